@@ -1,0 +1,172 @@
+// build_front.hip -- scene bounds + Morton codes (the front of RunBottomUpBuild).
+//
+// Replaces CalculateSceneAabb (Multiblock.cu:104-114) and GenerateMortonCodes
+// (BottomUpBuilder.cu:98-115).  HBM-bound streaming kernels: the 36-byte AoS triangles are read as a
+// flat float stream with 16-byte-per-lane loads (the reference reads float3 at a 12-byte stride and
+// issues 6 global atomics per triangle on one 24-byte address).
+#include "rt_device.hpp"
+#include "rt_launch.hpp"
+
+namespace rt {
+
+// ---------------------------------------------------------------------------------------------
+// Scene AABB.  Flat element e of the triangle array belongs to axis e % 3.  A thread strides by
+// gridDim.x*256 float4's, and the grid is a multiple of 3 blocks, so (float4 index) % 3 -- the axis
+// of the first element of every float4 a thread loads -- is constant per thread: min/max are kept in
+// that rotated frame and un-rotated once at the end.  Everything is folded in the ordered-int
+// domain (DeviceUtils.cuh:3-13), wave-reduced, block-reduced through LDS and finished with 6 integer
+// atomics per BLOCK (exact, order independent).
+__global__ __launch_bounds__(256) void scene_aabb_kernel(const float* __restrict__ f, uint64_t nfloats,
+                                                         int* __restrict__ aabb)
+{
+    const uint64_t nvec = nfloats >> 2;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const int r = (int)(q % 3);  // axis of element 0 of every float4 of this thread
+
+    int lo0 = 0x7f7fffff, lo1 = 0x7f7fffff, lo2 = 0x7f7fffff;
+    int hi0 = (int)0x80800000, hi1 = (int)0x80800000, hi2 = (int)0x80800000;
+    const float4* f4 = reinterpret_cast<const float4*>(f);
+    for (; q < nvec; q += stride) {
+        float4 v = f4[q];
+        int a = float_to_ordered_int(v.x), b = float_to_ordered_int(v.y);
+        int c = float_to_ordered_int(v.z), d = float_to_ordered_int(v.w);
+        lo0 = min(lo0, min(a, d)); hi0 = max(hi0, max(a, d));  // elements 0 and 3 share an axis
+        lo1 = min(lo1, b);         hi1 = max(hi1, b);
+        lo2 = min(lo2, c);         hi2 = max(hi2, c);
+    }
+    // un-rotate: frame slot s is axis (r + s) % 3
+    int lo[3], hi[3];
+    lo[0] = r == 0 ? lo0 : (r == 1 ? lo2 : lo1);
+    lo[1] = r == 0 ? lo1 : (r == 1 ? lo0 : lo2);
+    lo[2] = r == 0 ? lo2 : (r == 1 ? lo1 : lo0);
+    hi[0] = r == 0 ? hi0 : (r == 1 ? hi2 : hi1);
+    hi[1] = r == 0 ? hi1 : (r == 1 ? hi0 : hi2);
+    hi[2] = r == 0 ? hi2 : (r == 1 ? hi1 : hi0);
+    // tail (nfloats % 4 elements) by one thread
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (uint64_t e = nvec << 2; e < nfloats; e++) {
+            int v = float_to_ordered_int(f[e]);
+            int ax = (int)(e % 3);
+            lo[ax] = min(lo[ax], v);
+            hi[ax] = max(hi[ax], v);
+        }
+    }
+    __shared__ int red[4][6];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        int l = wave_min_i32(lo[k]), h = wave_max_i32(hi[k]);
+        if (lane == 0) { red[wave][k] = l; red[wave][3 + k] = h; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        int k = threadIdx.x;
+        int v = red[0][k];
+        if (k < 3) {
+            v = min(min(v, red[1][k]), min(red[2][k], red[3][k]));
+            atomicMin(&aabb[k], v);
+        } else {
+            v = max(max(v, red[1][k]), max(red[2][k], red[3][k]));
+            atomicMax(&aabb[k], v);
+        }
+    }
+}
+
+__global__ void reset_aabb_kernel(int* aabb)
+{
+    // BuildWrapper.cu:288-289: ordered-int "empty" box
+    if (threadIdx.x < 6) aabb[threadIdx.x] = threadIdx.x < 3 ? 0x7f7fffff : (int)0x80800000;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BottomUpBuilder.cu:12-32
+__device__ __forceinline__ uint32_t expand_bits(uint32_t v)
+{
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t morton3d(float x, float y, float z)
+{
+    x = fminf(fmaxf(x * 1024.0f, 0.0f), 1023.0f);
+    y = fminf(fmaxf(y * 1024.0f, 0.0f), 1023.0f);
+    z = fminf(fmaxf(z * 1024.0f, 0.0f), 1023.0f);
+    return expand_bits((uint32_t)x) * 4 + expand_bits((uint32_t)y) * 2 + expand_bits((uint32_t)z);
+}
+
+// Morton codes: one block = 256 triangles = 2304 floats staged through LDS with coalesced float4
+// loads; each thread then reads its 9 floats at a 9-dword stride (9 is odd: conflict-free).
+__global__ __launch_bounds__(256) void morton_kernel(uint32_t* __restrict__ codes, uint32_t* __restrict__ values,
+                                                     const float* __restrict__ f, const int* __restrict__ aabb,
+                                                     uint32_t n)
+{
+    __shared__ float s[256 * 9];
+    const uint64_t nfloats = (uint64_t)n * 9;
+    const uint64_t base = (uint64_t)blockIdx.x * (256 * 9);
+    const float4* f4 = reinterpret_cast<const float4*>(f + base);  // 9216-byte block stride: 16-B aligned
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        int q = threadIdx.x + k * 256;
+        if (q < 576) {
+            uint64_t e = base + (uint64_t)q * 4;
+            if (e + 4 <= nfloats) {
+                float4 v = f4[q];
+                s[q * 4 + 0] = v.x; s[q * 4 + 1] = v.y; s[q * 4 + 2] = v.z; s[q * 4 + 3] = v.w;
+            } else {
+                for (int j = 0; j < 4; j++)
+                    if (e + j < nfloats) s[q * 4 + j] = f[e + j];
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n) return;
+    const float* t = &s[threadIdx.x * 9];
+    // centre = (v0 + v1 + v2) / 3.0f, left-associated (BottomUpBuilder.cu:104-107)
+    float cx = ((t[0] + t[3]) + t[6]) / 3.0f;
+    float cy = ((t[1] + t[4]) + t[7]) / 3.0f;
+    float cz = ((t[2] + t[5]) + t[8]) / 3.0f;
+    const float minx = ordered_int_to_float(aabb[0]), miny = ordered_int_to_float(aabb[1]);
+    const float minz = ordered_int_to_float(aabb[2]), maxx = ordered_int_to_float(aabb[3]);
+    const float maxy = ordered_int_to_float(aabb[4]), maxz = ordered_int_to_float(aabb[5]);
+    cx = (cx - minx) / (maxx - minx);
+    cy = (cy - miny) / (maxy - miny);
+    cz = (cz - minz) / (maxz - minz);
+    // clamp(c, 0, 1) = fmaxf(0, fminf(c, 1))  (helper_math.h:1161-1164); NaN (flat axis) -> 1
+    cx = fmaxf(0.0f, fminf(cx, 1.0f));
+    cy = fmaxf(0.0f, fminf(cy, 1.0f));
+    cz = fmaxf(0.0f, fminf(cz, 1.0f));
+    codes[gid] = morton3d(cx, cy, cz);
+    values[gid] = gid;
+}
+
+// ---------------------------------------------------------------------------------------------
+hipError_t launch_reset_aabb(int* aabb, hipStream_t st)
+{
+    reset_aabb_kernel<<<1, 64, 0, st>>>(aabb);
+    return hipGetLastError();
+}
+
+hipError_t launch_scene_aabb(const rt_triangle* tris, uint32_t n, int* aabb, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    const uint64_t nfloats = (uint64_t)n * 9;
+    uint64_t want = (nfloats / 4 + 255) / 256;              // one float4 per thread
+    uint32_t blocks = (uint32_t)(want < 3 ? 3 : (want > 1536 ? 1536 : want));
+    blocks = (blocks + 2) / 3 * 3;                           // multiple of 3 (see kernel comment)
+    scene_aabb_kernel<<<blocks, 256, 0, st>>>(reinterpret_cast<const float*>(tris), nfloats, aabb);
+    return hipGetLastError();
+}
+
+hipError_t launch_morton(uint32_t* codes, uint32_t* values, const rt_triangle* tris, const int* aabb, uint32_t n,
+                         hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    morton_kernel<<<(n + 255) / 256, 256, 0, st>>>(codes, values, reinterpret_cast<const float*>(tris), aabb, n);
+    return hipGetLastError();
+}
+
+}  // namespace rt

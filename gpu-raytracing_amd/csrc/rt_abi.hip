@@ -1,0 +1,165 @@
+// rt_abi.hip -- the extern "C" entry points declared in include/rt_abi.h.
+// Host orchestration only: scratch carving and kernel order (the role of BuildWrapper.cu:68-136,
+// 253-362 and main.cu:125-192 in the reference).  No allocation, no synchronisation, no host<->device
+// copies: every call is a sequence of asynchronous launches on the caller's stream.
+#include "rt_device.hpp"
+#include "rt_launch.hpp"
+
+namespace rt {
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+BuLayout bu_layout(uint32_t n)
+{
+    BuLayout L;
+    const size_t nn = n ? n : 1;
+    size_t off = 0;
+    L.p_aabb = off;         off += 32;
+    L.status = off;         off += 32;
+    off = align_up(off, 256);
+    L.morton = off;         off = align_up(off + nn * 4, 256);
+    L.sorted_indices = off; off = align_up(off + nn * 4, 256);
+    L.tmp_keys = off;       off = align_up(off + nn * 4, 256);
+    L.tmp_vals = off;       off = align_up(off + nn * 4, 256);
+    L.sort = off;           off = align_up(off + sort_scratch_layout(n).total, 256);
+    L.levels = off;         off = align_up(off + lbvh_level_plan(n).total, 256);
+    L.hybrid = off;         off = align_up(off + 64 * 1024, 256);
+    L.total = off;
+    return L;
+}
+
+static inline int hip_rc(hipError_t e) { return e == hipSuccess ? RT_OK : RT_ERR_HIP_BASE - (int)e; }
+
+__global__ void clear_status_kernel(uint32_t* status)
+{
+    if (threadIdx.x < 8) status[threadIdx.x] = 0;
+}
+
+}  // namespace rt
+
+using namespace rt;
+
+extern "C" {
+
+size_t rt_bu_memory_requirements(uint32_t num_triangles) { return bu_layout(num_triangles).total; }
+
+size_t rt_nodes_bytes(uint32_t num_triangles)
+{
+    // main.cu:235-237: sizeof(Node) * (n + max(512, NUM_BLOCKS)) * 2 * 2
+    return sizeof(rt_node) * ((size_t)num_triangles + 512) * 4;
+}
+
+int rt_bu_scratch_layout_get(uint32_t num_triangles, rt_bu_scratch_layout* out)
+{
+    if (!out) return RT_ERR_INVALID_ARGUMENT;
+    const BuLayout L = bu_layout(num_triangles);
+    out->p_aabb = L.p_aabb;
+    out->morton = L.morton;
+    out->sorted_indices = L.sorted_indices;
+    out->total = L.total;
+    return RT_OK;
+}
+
+int rt_calculate_scene_aabb(const rt_triangle* triangles, uint32_t n, int32_t* aabb_ordered, void* stream)
+{
+    if (!aabb_ordered || (n && !triangles)) return RT_ERR_INVALID_ARGUMENT;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e = launch_reset_aabb(aabb_ordered, st);
+    if (e == hipSuccess) e = launch_scene_aabb(triangles, n, aabb_ordered, st);
+    return hip_rc(e);
+}
+
+int rt_generate_morton_codes(uint32_t* codes, uint32_t* values, const rt_triangle* triangles,
+                             const int32_t* aabb_ordered, uint32_t n, void* stream)
+{
+    if (n && (!codes || !values || !triangles || !aabb_ordered)) return RT_ERR_INVALID_ARGUMENT;
+    return hip_rc(launch_morton(codes, values, triangles, aabb_ordered, n, static_cast<hipStream_t>(stream)));
+}
+
+size_t rt_radix_sort_scratch_bytes(uint32_t count) { return sort_scratch_layout(count).total; }
+
+int rt_radix_sort_u32_pairs(uint32_t* keys, uint32_t* values, uint32_t* tmp_keys, uint32_t* tmp_values,
+                            uint32_t count, void* sort_scratch, void* stream)
+{
+    if (count && (!keys || !values || !tmp_keys || !tmp_values || !sort_scratch)) return RT_ERR_INVALID_ARGUMENT;
+    return hip_rc(launch_radix_sort(keys, values, tmp_keys, tmp_values, count, sort_scratch,
+                                    static_cast<hipStream_t>(stream)));
+}
+
+int rt_run_bottom_up_build(const rt_build_input* input, const rt_arguments* args, int hybrid, void* stream)
+{
+    if (!input || !input->nodes_out || !input->scratch) return RT_ERR_INVALID_ARGUMENT;
+    const uint32_t n = input->num_triangles;
+    if (n && (!input->triangles_in || !input->triangles_out)) return RT_ERR_INVALID_ARGUMENT;
+    if (n > (1u << 28)) return RT_ERR_TOO_LARGE;  // 2(n-1) slots must fit the 29-bit child field
+    if (args && (args->enable_pairs || args->enable_splits)) return RT_ERR_UNSUPPORTED;
+    if (hybrid) return RT_ERR_UNSUPPORTED;  // not built yet
+    if ((reinterpret_cast<uintptr_t>(input->scratch) & 255u) || (reinterpret_cast<uintptr_t>(input->triangles_in) & 15u) ||
+        (reinterpret_cast<uintptr_t>(input->triangles_out) & 63u) || (reinterpret_cast<uintptr_t>(input->nodes_out) & 63u))
+        return RT_ERR_INVALID_ARGUMENT;
+
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const BuLayout L = bu_layout(n);
+    char* s = static_cast<char*>(input->scratch);
+    int* p_aabb = reinterpret_cast<int*>(s + L.p_aabb);
+    uint32_t* status = reinterpret_cast<uint32_t*>(s + L.status);
+    uint32_t* morton = reinterpret_cast<uint32_t*>(s + L.morton);
+    uint32_t* sorted = reinterpret_cast<uint32_t*>(s + L.sorted_indices);
+    uint32_t* tmpk = reinterpret_cast<uint32_t*>(s + L.tmp_keys);
+    uint32_t* tmpv = reinterpret_cast<uint32_t*>(s + L.tmp_vals);
+
+    clear_status_kernel<<<1, 64, 0, st>>>(status);
+    hipError_t e = launch_reset_aabb(p_aabb, st);
+    if (e == hipSuccess) e = launch_scene_aabb(input->triangles_in, n, p_aabb, st);
+    if (e == hipSuccess) e = launch_morton(morton, sorted, input->triangles_in, p_aabb, n, st);
+    if (e == hipSuccess) e = launch_radix_sort(morton, sorted, tmpk, tmpv, n, s + L.sort, st);
+    if (e == hipSuccess)
+        e = launch_lbvh_levels(input->triangles_in, morton, sorted, n, input->triangles_out, input->nodes_out,
+                               s + L.levels, status, st);
+    return hip_rc(e);
+}
+
+int rt_trace(const rt_accel* as, const rt_scene* scene, uint64_t* counters, int render_type, uint8_t* rgba8,
+             uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t spp, void* stream)
+{
+    if (!as || !scene || !rgba8 || !as->nodes || !scene->camera) return RT_ERR_INVALID_ARGUMENT;
+    if (w == 0 || h == 0 || y0 > y1 || y1 > h || as->count > 7) return RT_ERR_INVALID_ARGUMENT;
+    if (spp == 0) spp = 1;
+    if (spp != 1 && spp != 4 && spp != 16) return RT_ERR_INVALID_ARGUMENT;
+    switch (render_type) {
+    case RT_RENDER_DEPTH: case RT_RENDER_BOXTESTS: case RT_RENDER_TRIANGLE_TESTS: break;
+    case RT_RENDER_MATERIAL_ID: case RT_RENDER_DIFFUSE:
+        if (!scene->attributes || !scene->materials || scene->num_materials == 0) return RT_ERR_INVALID_ARGUMENT;
+        break;
+    default: return RT_ERR_UNSUPPORTED;  // textured modes: SURVEY 8(f) rank 2
+    }
+    TraceLaunch t;
+    t.as = *as;
+    t.scene = *scene;
+    t.counters = counters;
+    t.render_type = render_type;
+    t.rgba8 = rgba8;
+    t.w = w; t.h = h; t.y0 = y0; t.y1 = y1; t.spp = spp;
+    return hip_rc(launch_trace(t, static_cast<hipStream_t>(stream)));
+}
+
+const char* rt_error_string(int code)
+{
+    switch (code) {
+    case RT_OK: return "ok";
+    case RT_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case RT_ERR_UNSUPPORTED: return "unsupported option (pairs / splits / SAH / hybrid / textured render type)";
+    case RT_ERR_TOO_LARGE: return "too many triangles for the 29-bit node index";
+    default: break;
+    }
+    if (code <= RT_ERR_HIP_BASE) return hipGetErrorString(static_cast<hipError_t>(RT_ERR_HIP_BASE - code));
+    return "unknown error";
+}
+
+const char* rt_version_string(void)
+{
+    return "rt_amd gfx950 | sort: LSD 4x8bit, tile 4096 | lbvh: LDS agglomerative, 1024 leaves/wg, fan 16 | "
+           "trace: wave64 8x8 tiles, LDS stack 24";
+}
+
+}  // extern "C"

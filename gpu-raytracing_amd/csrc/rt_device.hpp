@@ -1,0 +1,87 @@
+// rt_device.hpp -- shared device helpers and launch geometry for the gfx950 kernels.
+// Written for wave64 / CDNA4 only (no CUDA / multi-backend paths).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_abi.h"
+
+static_assert(sizeof(rt_triangle) == 36, "Triangle layout (Common.cuh:199)");
+static_assert(sizeof(rt_node) == 32, "Node layout (Common.cuh:152)");
+static_assert(sizeof(rt_triangle_pair) == 64, "TrianglePair layout (Common.cuh:161)");
+static_assert(sizeof(rt_camera) == 64, "Camera layout (Common.cuh:44)");
+static_assert(sizeof(rt_attributes) == 72, "Attributes layout (Common.cuh:55)");
+static_assert(sizeof(rt_material) == 52, "Material POD mirror");
+
+namespace rt {
+
+constexpr uint32_t kIndexMask = 0x1FFFFFFFu;  // 29-bit child / parent field (Common.cuh:152-159)
+
+// ---- DeviceUtils.cuh:3-13: monotone float <-> int so integer min/max == float min/max
+__device__ __forceinline__ int float_to_ordered_int(float f)
+{
+    int i = __float_as_int(f);
+    return (i >= 0) ? i : i ^ 0x7FFFFFFF;
+}
+__device__ __forceinline__ float ordered_int_to_float(int i)
+{
+    return __int_as_float((i >= 0) ? i : i ^ 0x7FFFFFFF);
+}
+
+// ---- wave64 helpers
+__device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// inclusive scan across the 64 lanes of a wave
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// exclusive scan of one value per thread over a block of NT threads (NT multiple of 64, <= 1024).
+// `ws` is NT/64 + 1 words of LDS.  Returns the exclusive prefix; *total gets the block sum.
+template <int NT>
+__device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* ws, uint32_t* total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NW = NT / 64;
+    uint32_t incl = wave_incl_scan_u32(v, lane);
+    if (lane == 63) ws[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t w = lane < NW ? ws[lane] : 0u;
+        uint32_t wi = wave_incl_scan_u32(w, lane);
+        if (lane < NW) ws[lane] = wi - w;
+        if (lane == NW - 1) ws[NW] = wi;
+    }
+    __syncthreads();
+    uint32_t r = ws[wave] + incl - v;
+    *total = ws[NW];
+    __syncthreads();
+    return r;
+}
+
+}  // namespace rt

@@ -1,0 +1,83 @@
+// rt_launch.hpp -- host-side launch functions of each kernel group and the scratch layout.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "rt_abi.h"
+
+namespace rt {
+
+// ---- radix sort geometry (radix_sort.hip)
+constexpr uint32_t kSortThreads = 256;
+constexpr uint32_t kSortItems = 16;
+constexpr uint32_t kSortTile = kSortThreads * kSortItems;  // keys per workgroup
+constexpr uint32_t kRadixBits = 8;
+constexpr uint32_t kRadix = 1u << kRadixBits;
+constexpr uint32_t kSortPasses = 4;
+
+inline uint32_t sort_num_tiles(uint32_t n) { return (n + kSortTile - 1) / kSortTile; }
+
+struct SortScratch {
+    size_t digit_total;  // uint32[kSortPasses][kRadix], zeroed before the sort
+    size_t hist;         // uint32[kRadix][num_tiles]
+    size_t offs;         // uint32[kRadix][num_tiles]
+    size_t total;
+};
+SortScratch sort_scratch_layout(uint32_t n);
+
+// ---- LBVH level geometry (lbvh_levels.hip)
+constexpr uint32_t kLeafCap = 1024;   // leaves per workgroup at the leaf level
+constexpr uint32_t kUpperFan = 16;    // previous-level workgroups folded by one upper-level workgroup
+constexpr uint32_t kMaxOpen = 128;    // open sub-tree roots a workgroup can emit (>= 2 * max tree depth 62)
+constexpr uint32_t kUpperCap = kUpperFan * kMaxOpen;  // 2048 segments per upper-level workgroup
+constexpr uint32_t kRecDwords = 12;   // segment record: f, l, desc, cc, min[3], max[3], pad[2]
+constexpr uint32_t kMaxLevels = 8;
+
+struct LevelPlan {
+    uint32_t num_levels;
+    uint32_t blocks[kMaxLevels];
+    size_t cnt_off[kMaxLevels];  // uint32[blocks]
+    size_t rec_off[kMaxLevels];  // uint32[blocks][kMaxOpen][kRecDwords]
+    size_t total;
+};
+LevelPlan lbvh_level_plan(uint32_t n);
+
+// ---- whole-build scratch layout
+struct BuLayout {
+    size_t p_aabb;          // int32[6]
+    size_t status;          // uint32[8]: [0] error flags
+    size_t morton;          // uint32[n]
+    size_t sorted_indices;  // uint32[n]
+    size_t tmp_keys;        // uint32[n]
+    size_t tmp_vals;        // uint32[n]
+    size_t sort;            // SortScratch
+    size_t levels;          // LevelPlan
+    size_t hybrid;          // hybrid top-tree work area
+    size_t total;
+};
+BuLayout bu_layout(uint32_t n);
+
+// ---- launches
+hipError_t launch_reset_aabb(int* aabb, hipStream_t st);
+hipError_t launch_scene_aabb(const rt_triangle* tris, uint32_t n, int* aabb, hipStream_t st);
+hipError_t launch_morton(uint32_t* codes, uint32_t* values, const rt_triangle* tris, const int* aabb, uint32_t n,
+                         hipStream_t st);
+hipError_t launch_radix_sort(uint32_t* keys, uint32_t* vals, uint32_t* tmp_keys, uint32_t* tmp_vals, uint32_t n,
+                             void* sort_scratch, hipStream_t st);
+hipError_t launch_lbvh_levels(const rt_triangle* tris, const uint32_t* codes, const uint32_t* sorted_indices,
+                              uint32_t n, rt_triangle_pair* leaves, rt_node* nodes, void* level_scratch,
+                              uint32_t* status, hipStream_t st);
+
+struct TraceLaunch {
+    rt_accel as;
+    rt_scene scene;
+    uint64_t* counters;
+    int render_type;
+    uint8_t* rgba8;
+    uint32_t w, h, y0, y1, spp;
+};
+hipError_t launch_trace(const TraceLaunch& t, hipStream_t st);
+
+}  // namespace rt

@@ -1,0 +1,345 @@
+// trace_kernel.hip -- primary-ray generation, BVH traversal, intersection, shading, RGBA8 store.
+//
+// Replaces TraceRays / TraceRay / IntersectRayAabb / IntersectRayTriangle(Pair) / AmbientShader
+// (Tracer.cu:187-200, 256-374, 376-469, 471-595).  Semantics (and therefore the per-ray box/triangle
+// test counts, which are OUTPUTS of the kBoxtests / kTriangleTests modes) follow the reference
+// exactly: children visited in slot order, leaf hits intersected immediately, nearest Box child
+// continued first (ties: larger child index), the others pushed in encounter order, popped entries
+// are not re-culled.  Machine mapping for wave64:
+//   * one wave = one 8x8 pixel tile (Morton order inside the tile) so the 64 rays of a wave walk
+//     the same upper tree and their 64-byte sibling-pair loads coalesce;
+//   * a sibling pair (2 x 32-byte slots, 64-byte aligned) is fetched with four 16-byte loads issued
+//     together, before either box is tested;
+//   * the traversal stack is a lane-interleaved LDS column (conflict-free: bank = lane % 32 for both
+//     32-lane halves), entries are one packed dword child:29|count:3; entries beyond the LDS depth
+//     spill to private memory (never on the bench scenes);
+//   * the reference's push-then-pop of the nearest child is kept in a register instead;
+//   * 1/direction is computed once per ray (bit-identical to recomputing it per box: IEEE division);
+//   * test counters are wave-reduced and added with ONE 64-bit atomic per wave (reference: one per ray);
+//   * workgroups are dealt to XCDs round-robin by the hardware, so the tile order is remapped to give
+//     each XCD a contiguous band of the image (its L2 then holds one region of the tree).
+// Compiled with -ffp-contract=off: results are bit-identical to the C oracle.
+#include "rt_device.hpp"
+#include "rt_launch.hpp"
+
+namespace rt {
+
+constexpr int kStackLds = 24;    // LDS-resident stack entries per lane
+constexpr int kStackMax = 64;    // reference stack size (Tracer.cu:314)
+constexpr int kTraceWaves = 4;
+
+struct TraceParams {
+    const rt_node* nodes;
+    const rt_triangle_pair* leaves;
+    const rt_attributes* attributes;
+    const rt_material* materials;
+    const rt_camera* camera;
+    float light[3];
+    uint32_t root, count, num_materials;
+    uint8_t* rgba8;
+    uint32_t w, h, y0, y1, spp;
+    int render_type;
+    unsigned long long* counters;
+    uint32_t tiles_x, num_tiles;
+};
+
+struct Ray {
+    float ox, oy, oz, dx, dy, dz, ix, iy, iz, tmin, tmax;
+};
+struct Hit {
+    uint32_t primitive_id, tri_id;
+    float bu, bv;
+};
+
+// Tracer.cu:256-291
+__device__ __forceinline__ bool intersect_tri(float v0x, float v0y, float v0z, float v1x, float v1y, float v1z,
+                                              float v2x, float v2y, float v2z, Ray& r, Hit& h, uint32_t tri_id,
+                                              uint32_t prim_id)
+{
+    const float epsilon = 0.000000001f;
+    const float e1x = v1x - v0x, e1y = v1y - v0y, e1z = v1z - v0z;
+    const float e2x = v2x - v0x, e2y = v2y - v0y, e2z = v2z - v0z;
+    const float hx = r.dy * e2z - r.dz * e2y, hy = r.dz * e2x - r.dx * e2z, hz = r.dx * e2y - r.dy * e2x;
+    const float a = e1x * hx + e1y * hy + e1z * hz;
+    if (a > -epsilon && a < epsilon) return false;
+    const float f = 1.0f / a;
+    const float sx = r.ox - v0x, sy = r.oy - v0y, sz = r.oz - v0z;
+    const float u = f * (sx * hx + sy * hy + sz * hz);
+    if (u < 0.0f || u > 1.0f) return false;
+    const float qx = sy * e1z - sz * e1y, qy = sz * e1x - sx * e1z, qz = sx * e1y - sy * e1x;
+    const float v = f * (r.dx * qx + r.dy * qy + r.dz * qz);
+    if (v < 0.0f || (u + v) > 1.0f) return false;
+    const float t = f * (e2x * qx + e2y * qy + e2z * qz);
+    if (t < r.tmin || t > r.tmax) return false;
+    r.tmax = t;
+    h.primitive_id = prim_id;
+    h.tri_id = tri_id;
+    h.bu = u;
+    h.bv = v;
+    return true;
+}
+
+struct Stack {
+    uint32_t* lds;  // this lane's column: entry k at lds[k * 64]
+    uint32_t spill[kStackMax - kStackLds];
+    int sp;
+    __device__ __forceinline__ void push(uint32_t e)
+    {
+        if (sp < kStackLds) lds[sp * 64] = e;
+        else if (sp < kStackMax) spill[sp - kStackLds] = e;
+        if (sp < kStackMax) sp++;  // a 65th push is dropped (the reference overruns its array, Tracer.cu:353-369)
+    }
+    __device__ __forceinline__ uint32_t pop()
+    {
+        --sp;
+        return sp < kStackLds ? lds[sp * 64] : spill[sp - kStackLds];
+    }
+};
+
+// Tracer.cu:308-374
+__device__ __forceinline__ bool trace_ray(const TraceParams& p, Ray& r, Hit& h, uint32_t& box_tests,
+                                          uint32_t& tri_tests, Stack& st)
+{
+    bool tri_hit = false;
+    st.sp = 0;
+    uint32_t cur = (p.root & kIndexMask) | (p.count << 29);
+    while (true) {
+        const uint32_t index = cur & kIndexMask, cnt = cur >> 29;
+        bool have_near = false;
+        uint32_t near_e = 0;
+        float near_d = 0.0f;
+        const uint4* np = reinterpret_cast<const uint4*>(p.nodes + index);
+        for (uint32_t i = 0; i < cnt; i += 2) {
+            uint4 q[4];
+            q[0] = np[i * 2 + 0];
+            q[1] = np[i * 2 + 1];
+            const bool two = i + 1 < cnt;
+            if (two) { q[2] = np[i * 2 + 2]; q[3] = np[i * 2 + 3]; }
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                if (k == 1 && !two) break;
+                const uint4 a = q[k * 2], b = q[k * 2 + 1];
+                const uint32_t type = b.w >> 29, child = b.w & kIndexMask, ncount = a.w >> 29;
+                if (type == RT_CHILD_NONE) continue;
+                // IntersectRayAabb (Tracer.cu:187-200)
+                const float t1x = (__uint_as_float(a.x) - r.ox) * r.ix, t2x = (__uint_as_float(b.x) - r.ox) * r.ix;
+                const float t1y = (__uint_as_float(a.y) - r.oy) * r.iy, t2y = (__uint_as_float(b.y) - r.oy) * r.iy;
+                const float t1z = (__uint_as_float(a.z) - r.oz) * r.iz, t2z = (__uint_as_float(b.z) - r.oz) * r.iz;
+                const float front = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
+                const float back = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
+                const bool hit = back >= front && front <= r.tmax && back >= r.tmin;
+                box_tests++;
+                if (!hit) continue;
+                const uint32_t e = child | (ncount << 29);
+                if (type == RT_CHILD_TRI) {
+                    tri_tests++;
+                    const uint4* tp = reinterpret_cast<const uint4*>(p.leaves + child);
+                    const uint4 l0 = tp[0], l1 = tp[1], l2 = tp[2], l3 = tp[3];
+                    // IntersectRayTrianglePair (Tracer.cu:293-306): A = (v0,v1,v2), B = (v2,v1,v3).  B is
+                    // requested whenever count > 0; for a single triangle v3 == v2 bit for bit, edge2 of B
+                    // is exactly 0, a == 0 and the reference rejects it -- skipped here with the same result.
+                    bool hit_tri = intersect_tri(__uint_as_float(l0.x), __uint_as_float(l0.y), __uint_as_float(l0.z),
+                                                 __uint_as_float(l1.x), __uint_as_float(l1.y), __uint_as_float(l1.z),
+                                                 __uint_as_float(l2.x), __uint_as_float(l2.y), __uint_as_float(l2.z),
+                                                 r, h, child << 1, l0.w);
+                    if (ncount > 0 && (l3.x != l2.x || l3.y != l2.y || l3.z != l2.z))
+                        hit_tri |= intersect_tri(__uint_as_float(l2.x), __uint_as_float(l2.y), __uint_as_float(l2.z),
+                                                 __uint_as_float(l1.x), __uint_as_float(l1.y), __uint_as_float(l1.z),
+                                                 __uint_as_float(l3.x), __uint_as_float(l3.y), __uint_as_float(l3.z),
+                                                 r, h, (child << 1) + 1, l1.w);
+                    tri_hit |= hit_tri;
+                } else if (!have_near) {
+                    near_e = e;
+                    near_d = front;
+                    have_near = true;
+                } else if (front < near_d || (front == near_d && child > (near_e & kIndexMask))) {
+                    st.push(near_e);
+                    near_e = e;
+                    near_d = front;
+                } else {
+                    st.push(e);
+                }
+            }
+        }
+        if (have_near) cur = near_e;          // the reference pushes it last and pops it first
+        else if (st.sp == 0) break;
+        else cur = st.pop();
+    }
+    return tri_hit;
+}
+
+__device__ __forceinline__ float clampf(float f, float a, float b) { return fmaxf(a, fminf(f, b)); }
+
+// Tracer.cu:15-41 (float rgb 0..255 before the uchar truncation)
+__device__ __forceinline__ void hsv_to_rgb255(float h, float s, float v, float& R, float& G, float& B)
+{
+    h = clampf(h, 0.f, 1.f) * 360.0f;
+    s = clampf(s, 0.f, 1.f);
+    v = clampf(v, 0.f, 1.f);
+    const float c = s * v;
+    const float x = c * (1 - fabsf(((int)h % 120) / 60.0f - 1));
+    const float m = v - c;
+    float r, g, b;
+    if (h >= 0 && h < 60) { r = c; g = x; b = 0; }
+    else if (h >= 60 && h < 120) { r = x; g = c; b = 0; }
+    else if (h >= 120 && h < 180) { r = 0; g = c; b = x; }
+    else if (h >= 180 && h < 240) { r = 0; g = x; b = c; }
+    else if (h >= 240 && h < 300) { r = x; g = 0; b = c; }
+    else { r = c; g = 0; b = x; }
+    R = (r + m) * 255; G = (g + m) * 255; B = (b + m) * 255;
+}
+
+// one sample of one pixel -> float colour 0..255 per channel (TraceRays body, Tracer.cu:482-593)
+__device__ __forceinline__ void shade_sample(const TraceParams& p, const rt_camera& cam, uint32_t x, uint32_t y,
+                                             float ox, float oy, Stack& st, uint32_t& box_acc, uint32_t& tri_acc,
+                                             float& R, float& G, float& B)
+{
+    const float ndcx = 2 * (((float)x + ox) / (float)p.w) - 1;
+    const float ndcy = 2 * (((float)y + oy) / (float)p.h) - 1;
+    const float px = (ndcx * cam.u.x + ndcy * cam.v.x) + 1.0f * cam.w.x;
+    const float py = (ndcx * cam.u.y + ndcy * cam.v.y) + 1.0f * cam.w.y;
+    const float pz = (ndcx * cam.u.z + ndcy * cam.v.z) + 1.0f * cam.w.z;
+    const float inv_len = 1.0f / sqrtf(px * px + py * py + pz * pz);  // normalize = v * rsqrtf(dot) (helper_math.h:1318)
+    const float max_depth = cam.max_depth;
+    Ray r;
+    r.dx = px * inv_len; r.dy = py * inv_len; r.dz = pz * inv_len;
+    r.ox = cam.position.x; r.oy = cam.position.y; r.oz = cam.position.z;
+    r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
+    r.tmin = 0.00001f;
+    r.tmax = max_depth;
+    Hit h = {0u, 0u, 0.f, 0.f};
+    uint32_t box_tests = 0, tri_tests = 0;
+    const bool hit = trace_ray(p, r, h, box_tests, tri_tests, st);
+    box_acc += box_tests;
+    tri_acc += tri_tests;
+    const float depth = hit ? r.tmax : 0.0f;
+
+    if (p.render_type == RT_RENDER_DEPTH) {
+        R = G = B = fminf(1.0f, depth / max_depth) * 255;
+        return;
+    }
+    if (p.render_type == RT_RENDER_BOXTESTS) {
+        R = 0;
+        G = B = fminf(box_tests / 180.0f, 1.0f) * 255;
+        return;
+    }
+    if (p.render_type == RT_RENDER_TRIANGLE_TESTS) {
+        const float g = fminf(tri_tests / 32.0f, 1.0f);
+        R = g * 100; G = g * 255; B = g * 100;
+        return;
+    }
+    R = G = B = 0;
+    if (!hit) return;
+    // RotateAttributes (Tracer.cu:57-82)
+    const rt_triangle_pair* pair = p.leaves + (h.tri_id >> 1);
+    const uint32_t rot = (h.tri_id & 1) ? pair->rotations[1] : pair->rotations[0];
+    const rt_attributes* at = p.attributes + h.primitive_id;
+    const int i0 = rot == 1 ? 2 : (rot == 2 ? 1 : 0);
+    const int i1 = rot == 1 ? 0 : (rot == 2 ? 2 : 1);
+    const int i2 = rot == 1 ? 1 : (rot == 2 ? 0 : 2);
+    const int material_id = at->material_id;
+    if (p.render_type == RT_RENDER_MATERIAL_ID) {
+        hsv_to_rgb255((float)material_id / p.num_materials, 1.0f, 1.0f, R, G, B);
+        return;
+    }
+    // kDiffuse: AmbientShader(use_textures = use_shadows = use_bump = false) (Tracer.cu:376-469)
+    const rt_material mat = p.materials[material_id];
+    const rt_float3 n0 = at->normal[i0], n1 = at->normal[i1], n2 = at->normal[i2];
+    const float hx = r.ox + r.dx * r.tmax, hy = r.oy + r.dy * r.tmax, hz = r.oz + r.dz * r.tmax;
+    const float w0 = 1 - h.bu - h.bv;
+    const float nx = (n0.x * w0 + n1.x * h.bu) + n2.x * h.bv;
+    const float ny = (n0.y * w0 + n1.y * h.bu) + n2.y * h.bv;
+    const float nz = (n0.z * w0 + n1.z * h.bu) + n2.z * h.bv;
+    float lx = p.light[0] - hx, ly = p.light[1] - hy, lz = p.light[2] - hz;
+    const float linv = 1.0f / sqrtf(lx * lx + ly * ly + lz * lz);
+    lx *= linv; ly *= linv; lz *= linv;
+    const float lcx = 1.0f, lcy = 0.9f, lcz = 0.8f;
+    const float dterm = 1.0f * fmaxf(nx * lx + ny * ly + nz * lz, 0.0f);
+    // reflect(-l, n) = -l - 2.0f * n * dot(n, -l)   (helper_math.h:1435-1438)
+    const float nlx = -lx, nly = -ly, nlz = -lz;
+    const float ndl = nx * nlx + ny * nly + nz * nlz;
+    const float rx = nlx - (nx * 2.0f) * ndl, ry = nly - (ny * 2.0f) * ndl, rz = nlz - (nz * 2.0f) * ndl;
+    // pow(max(dot(-dir, refl), 0.0), Ns): double max, double pow, narrowed by operator*(float, float3)
+    const double sb = fmax((double)((-r.dx) * rx + (-r.dy) * ry + (-r.dz) * rz), 0.0);
+    const float sp = (float)(1.0f * pow(sb, (double)mat.specular_exp));
+    float cr = ((lcx * dterm) * mat.diffuse.x + (lcx * 0.2f) * mat.ambient.x) + (lcx * sp) * mat.specular.x;
+    float cg = ((lcy * dterm) * mat.diffuse.y + (lcy * 0.2f) * mat.ambient.y) + (lcy * sp) * mat.specular.y;
+    float cb = ((lcz * dterm) * mat.diffuse.z + (lcz * 0.2f) * mat.ambient.z) + (lcz * sp) * mat.specular.z;
+    R = clampf(cr, 0.0f, 1.0f) * 255;
+    G = clampf(cg, 0.0f, 1.0f) * 255;
+    B = clampf(cb, 0.0f, 1.0f) * 255;
+}
+
+__global__ __launch_bounds__(kTraceWaves * 64) void trace_kernel(TraceParams p)
+{
+    __shared__ uint32_t stack_lds[kTraceWaves][kStackLds][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    // XCD-aware remap: hardware deals workgroup b to XCD b % 8; give XCD x a contiguous run of tiles.
+    const uint32_t nb = gridDim.x, bid = blockIdx.x;
+    const uint32_t per = nb >> 3, rem = nb & 7u, xcd = bid & 7u, loc = bid >> 3;
+    const uint32_t vb = xcd * per + min(xcd, rem) + loc;
+    const uint32_t tile = vb * kTraceWaves + wave;
+
+    // lane -> pixel inside the 8x8 tile, Morton order
+    const uint32_t lx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4);
+    const uint32_t ly = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
+    const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    const uint32_t x = tx * 8 + lx, y = p.y0 + ty * 8 + ly;
+    const bool active = tile < p.num_tiles && x < p.w && y < p.y1;
+
+    uint32_t box_acc = 0, tri_acc = 0;
+    if (active) {
+        const rt_camera cam = *p.camera;
+        Stack st;
+        st.lds = &stack_lds[wave][0][lane];
+        float R, G, B;
+        if (p.spp <= 1) {
+            shade_sample(p, cam, x, y, 0.5f, 0.5f, st, box_acc, tri_acc, R, G, B);
+        } else {
+            float ar = 0, ag = 0, ab = 0;
+            for (uint32_t s = 0; s < p.spp; s++) {
+                const float ox = ((float)(s % 4) + 0.5f) / 4.0f, oy = ((float)((s / 4) % 4) + 0.5f) / 4.0f;
+                shade_sample(p, cam, x, y, ox, oy, st, box_acc, tri_acc, R, G, B);
+                ar += R; ag += G; ab += B;
+            }
+            R = ar / (float)p.spp; G = ag / (float)p.spp; B = ab / (float)p.spp;
+        }
+        const uint32_t px = (uint32_t)(uint8_t)R | ((uint32_t)(uint8_t)G << 8) | ((uint32_t)(uint8_t)B << 16) | 0xFF000000u;
+        reinterpret_cast<uint32_t*>(p.rgba8)[(size_t)y * p.w + x] = px;
+    }
+    if (p.counters) {
+        const uint32_t bsum = wave_sum_u32(box_acc), tsum = wave_sum_u32(tri_acc);  // <= 64 * 2^26: no overflow per wave
+        if (lane == 0 && (bsum | tsum)) {
+            atomicAdd(&p.counters[0], (unsigned long long)bsum);
+            atomicAdd(&p.counters[1], (unsigned long long)tsum);
+        }
+    }
+}
+
+hipError_t launch_trace(const TraceLaunch& t, hipStream_t st)
+{
+    if (t.y1 <= t.y0 || t.w == 0) return hipSuccess;
+    TraceParams p;
+    p.nodes = t.as.nodes;
+    p.leaves = t.as.triangles;
+    p.attributes = t.scene.attributes;
+    p.materials = t.scene.materials;
+    p.camera = t.scene.camera;
+    p.light[0] = t.scene.light[0]; p.light[1] = t.scene.light[1]; p.light[2] = t.scene.light[2];
+    p.root = t.as.root;
+    p.count = t.as.count;
+    p.num_materials = t.scene.num_materials;
+    p.rgba8 = t.rgba8;
+    p.w = t.w; p.h = t.h; p.y0 = t.y0; p.y1 = t.y1; p.spp = t.spp;
+    p.render_type = t.render_type;
+    p.counters = reinterpret_cast<unsigned long long*>(t.counters);
+    p.tiles_x = (t.w + 7) / 8;
+    const uint32_t tiles_y = (t.y1 - t.y0 + 7) / 8;
+    p.num_tiles = p.tiles_x * tiles_y;
+    const uint32_t blocks = (p.num_tiles + kTraceWaves - 1) / kTraceWaves;
+    trace_kernel<<<blocks, kTraceWaves * 64, 0, st>>>(p);
+    return hipGetLastError();
+}
+
+}  // namespace rt

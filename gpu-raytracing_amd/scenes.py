@@ -1,0 +1,145 @@
+"""Synthetic scenes and cameras for the parity tests and the bench.
+
+Every generator is libm-free (integer hash -> float by exact scaling) so the triangles are bit-identical on
+every machine.  Cameras are built with float32 numpy arithmetic following UpdateCamera
+(reference src/Camera.cu:8-29); they are INPUTS handed identically to the oracle and to the GPU path, so parity
+never depends on the host's sin/cos.
+"""
+from __future__ import annotations
+
+import importlib
+
+import numpy as np
+
+_pkg = importlib.import_module(__package__) if __package__ else None
+CAMERA = _pkg.CAMERA if _pkg else None
+ATTRIBUTES = _pkg.ATTRIBUTES if _pkg else None
+MATERIAL = _pkg.MATERIAL if _pkg else None
+
+
+def pcg_hash(x: np.ndarray) -> np.ndarray:
+    """PCG-RXS-M-XS 32-bit output hash on uint32 arrays."""
+    x = x.astype(np.uint32)
+    with np.errstate(over="ignore"):
+        state = x * np.uint32(747796405) + np.uint32(2891336453)
+        word = ((state >> ((state >> np.uint32(28)) + np.uint32(4))) ^ state) * np.uint32(277803737)
+        return (word >> np.uint32(22)) ^ word
+
+
+def grid_mesh(G: int, seed: int = 1) -> np.ndarray:
+    """Height-field of G x G cells, 2 triangles per cell: returns float32 [2*G*G, 9].
+
+    P(i,j) = (float(i), 2*h01(i,j), float(j)), h01 = (pcg_hash(i + 0x9E3779B9*j + seed) >> 8) * 2^-24; cells row-major
+    (j outer); each cell emits (P00,P10,P01) then (P10,P11,P01).  G=708 -> 1,002,528 tris; G=2237 -> 10,008,338.
+    """
+    i = np.arange(G + 1, dtype=np.uint32)[None, :]
+    j = np.arange(G + 1, dtype=np.uint32)[:, None]
+    with np.errstate(over="ignore"):
+        key = i + np.uint32(0x9E3779B9) * j + np.uint32(seed)
+    h01 = (pcg_hash(key) >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
+    P = np.empty((G + 1, G + 1, 3), dtype=np.float32)  # [j, i]
+    P[..., 0] = np.arange(G + 1, dtype=np.float32)[None, :]
+    P[..., 1] = np.float32(2.0) * h01
+    P[..., 2] = np.arange(G + 1, dtype=np.float32)[:, None]
+    p00, p10, p01, p11 = P[:-1, :-1], P[:-1, 1:], P[1:, :-1], P[1:, 1:]
+    tris = np.empty((G, G, 2, 3, 3), dtype=np.float32)
+    tris[:, :, 0, 0], tris[:, :, 0, 1], tris[:, :, 0, 2] = p00, p10, p01
+    tris[:, :, 1, 0], tris[:, :, 1, 1], tris[:, :, 1, 2] = p10, p11, p01
+    return tris.reshape(-1, 9)
+
+
+def soup(n: int, seed: int = 7, dup_fraction: float = 0.25, size: float = 0.02) -> np.ndarray:
+    """n small random triangles in the unit cube; `dup_fraction` of them are exact copies of other triangles
+    (equal centroids -> equal Morton codes -> exercises the index tie-break of cpl, BottomUpBuilder.cu:34-38)."""
+    idx = np.arange(n * 9, dtype=np.uint32)
+    r = (pcg_hash(idx + np.uint32(seed * 0x01000193)) >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
+    r = r.reshape(n, 3, 3)
+    centre = r[:, 0, :].copy()
+    tris = np.empty((n, 3, 3), dtype=np.float32)
+    tris[:, 0] = centre
+    tris[:, 1] = centre + (r[:, 1] - np.float32(0.5)) * np.float32(size)
+    tris[:, 2] = centre + (r[:, 2] - np.float32(0.5)) * np.float32(size)
+    ndup = int(n * dup_fraction)
+    if ndup:
+        src = (pcg_hash(np.arange(ndup, dtype=np.uint32) + np.uint32(seed + 99)) % np.uint32(max(n - ndup, 1))).astype(np.int64)
+        tris[n - ndup:] = tris[src]
+    return tris.reshape(n, 9)
+
+
+def flat_mesh(G: int, seed: int = 3) -> np.ndarray:
+    """Grid with every y equal: the scene box is flat on y, (c-min)/(max-min) = 0/0 = NaN, clamp -> 1
+    (SURVEY 'hard parts': the NaN clamp path of GenerateMortonCodes)."""
+    t = grid_mesh(G, seed).reshape(-1, 3, 3)
+    t[:, :, 1] = np.float32(0.25)
+    return t.reshape(-1, 9)
+
+
+def _normalize(v: np.ndarray) -> np.ndarray:
+    v = v.astype(np.float32)
+    d = np.float32(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])
+    return (v * (np.float32(1.0) / np.sqrt(d, dtype=np.float32))).astype(np.float32)
+
+
+def _cross(a, b):
+    return np.array([a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]], dtype=np.float32)
+
+
+def make_camera(position, yaw: float, pitch: float, max_depth: float, scale: float = 1.0) -> np.ndarray:
+    """Camera record with the u,v,w basis of UpdateCamera (Camera.cu:8-29)."""
+    cam = np.zeros(1, dtype=CAMERA)
+    yaw32, pitch32 = np.float32(yaw), np.float32(pitch)
+    w = np.array([-np.sin(yaw32) * np.cos(pitch32), -np.sin(pitch32), np.cos(yaw32) * np.cos(pitch32)], dtype=np.float32)
+    w = _normalize(w)
+    u = _normalize(_cross(w, np.array([0, 1, 0], dtype=np.float32)))
+    v = _normalize(_cross(w, u))
+    cam["position"] = np.asarray(position, dtype=np.float32)
+    cam["pitch"], cam["yaw"], cam["scale"], cam["max_depth"] = pitch32, yaw32, np.float32(scale), np.float32(max_depth)
+    cam["w"], cam["u"], cam["v"] = w, u, v
+    return cam
+
+
+def camera_a(G: int) -> np.ndarray:
+    """'top-down' headline camera of SURVEY 8(d): 100 % coverage, coherent rays."""
+    return make_camera((G / 2, 0.45 * G, G / 2), 0.0, 1.5, 1.5 * G)
+
+
+def camera_b(G: int) -> np.ndarray:
+    """'oblique' divergence-stress camera of SURVEY 8(d): partial coverage."""
+    return make_camera((-0.3 * G, 0.5 * G, -0.3 * G), -0.8, 0.3, 1.5 * G)
+
+
+def camera_for_box(bmin, bmax, yaw=0.6, pitch=0.45, back=1.4) -> np.ndarray:
+    """A camera outside an arbitrary scene box looking at its centre region (test scenes)."""
+    bmin, bmax = np.asarray(bmin, np.float32), np.asarray(bmax, np.float32)
+    centre, ext = (bmin + bmax) * np.float32(0.5), bmax - bmin
+    cam = make_camera(centre, yaw, pitch, float(ext.max()) * 4.0)
+    cam["position"] = centre - cam["w"][0] * np.float32(back * float(ext.max()))
+    return cam
+
+
+def flat_attributes(triangles: np.ndarray, material_ids=None) -> np.ndarray:
+    """Attributes as LoadOBJFromFile makes them without vn/vt (FileIO.cpp:88-93,415-430): the flat normal
+    normalize(cross(v1-v0, v2-v1)) on all three corners, uv = 0."""
+    t = triangles.reshape(-1, 3, 3).astype(np.float32)
+    e1, e2 = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1]
+    c = np.stack([e1[:, 1] * e2[:, 2] - e1[:, 2] * e2[:, 1], e1[:, 2] * e2[:, 0] - e1[:, 0] * e2[:, 2],
+                  e1[:, 0] * e2[:, 1] - e1[:, 1] * e2[:, 0]], axis=1).astype(np.float32)
+    d = (c[:, 0] * c[:, 0] + c[:, 1] * c[:, 1] + c[:, 2] * c[:, 2]).astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        nrm = (c * (np.float32(1.0) / np.sqrt(d, dtype=np.float32))[:, None]).astype(np.float32)
+    at = np.zeros(t.shape[0], dtype=ATTRIBUTES)
+    at["normal"] = nrm[:, None, :]
+    at["material_id"] = 0 if material_ids is None else material_ids
+    return at
+
+
+def default_materials(k: int = 3) -> np.ndarray:
+    m = np.zeros(k, dtype=MATERIAL)
+    pal = np.array([[0.8, 0.3, 0.2], [0.2, 0.7, 0.3], [0.25, 0.35, 0.9], [0.9, 0.8, 0.2]], dtype=np.float32)
+    for i in range(k):
+        m[i]["ambient"] = pal[i % 4] * np.float32(0.5)
+        m[i]["diffuse"] = pal[i % 4]
+        m[i]["specular"] = np.float32(0.5)
+        m[i]["specular_exp"] = np.float32(10.0 + 7 * i)
+        m[i]["texture"] = m[i]["bump"] = m[i]["disp"] = -1
+    return m

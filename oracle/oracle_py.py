@@ -1,0 +1,179 @@
+"""ctypes front-end of the CPU oracle (oracle/liboracle.so) and of the reference's own hierarchy checker
+(oracle/_ref/libref_utilities.so = /root/reference/src/Utilities.cpp compiled unmodified).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by
+the product package.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+REF_PATH = os.path.join(_HERE, "_ref", "libref_utilities.so")
+
+NODE = np.dtype([("min", "<f4", 3), ("w12", "<u4"), ("max", "<f4", 3), ("w28", "<u4")])
+TRIANGLE_PAIR = np.dtype([("v0", "<f4", 3), ("primitive_id_0", "<u4"), ("v1", "<f4", 3), ("primitive_id_1", "<u4"),
+                          ("v2", "<f4", 3), ("rotations", "<u2", 2), ("v3", "<f4", 3), ("pad3", "<f4")])
+
+_lib = None
+
+
+def build() -> None:
+    subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = ctypes.CDLL(LIB_PATH)
+        vp, u32 = ctypes.c_void_p, ctypes.c_uint32
+        L.ora_set_threads.argtypes = [ctypes.c_int]
+        L.ora_get_threads.restype = ctypes.c_int
+        L.ora_scene_aabb.argtypes = [vp, u32, vp]
+        L.ora_morton_codes.argtypes = [vp, u32, vp, vp, vp]
+        L.ora_radix_sort.argtypes = [vp, vp, vp, vp, u32]
+        L.ora_build.argtypes = [vp, u32, vp, vp, vp, vp, vp]
+        L.ora_count_nodes.argtypes = [vp, u32, u32, vp]
+        L.ora_verify_hierarchy.argtypes = [vp, u32, u32]
+        L.ora_verify_hierarchy.restype = ctypes.c_int
+        L.ora_trace.argtypes = [vp, vp, u32, u32, vp, vp, u32, vp, vp, ctypes.c_int, vp, u32, u32, u32, u32, u32, vp]
+        L.ora_trace.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def set_threads(n: int) -> None:
+    lib().ora_set_threads(int(n))
+
+
+def scene_aabb(tris: np.ndarray) -> np.ndarray:
+    t = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1, 9)
+    out = np.zeros(6, dtype=np.int32)
+    lib().ora_scene_aabb(_p(t), t.shape[0], _p(out))
+    return out
+
+
+def ordered_to_float(a: np.ndarray) -> np.ndarray:
+    a = np.asarray(a, dtype=np.int32)
+    return np.where(a >= 0, a, a ^ np.int32(0x7FFFFFFF)).astype(np.int32).view(np.float32)
+
+
+def morton_codes(tris: np.ndarray, aabb_ordered: np.ndarray):
+    t = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1, 9)
+    n = t.shape[0]
+    codes, vals = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+    a = np.ascontiguousarray(aabb_ordered, dtype=np.int32)
+    lib().ora_morton_codes(_p(t), n, _p(a), _p(codes), _p(vals))
+    return codes, vals
+
+
+def radix_sort(keys: np.ndarray, vals: np.ndarray):
+    k, v = np.ascontiguousarray(keys, np.uint32).copy(), np.ascontiguousarray(vals, np.uint32).copy()
+    tk, tv = np.zeros_like(k), np.zeros_like(v)
+    lib().ora_radix_sort(_p(k), _p(v), _p(tk), _p(tv), k.shape[0])
+    return k, v
+
+
+def build_bvh(tris: np.ndarray) -> dict:
+    """RunBottomUpBuild on the CPU: returns nodes (2*max(n-1,1) slots), leaves, sorted codes/indices, scene box."""
+    t = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1, 9)
+    n = t.shape[0]
+    nodes = np.zeros(2 * max(n - 1, 1), dtype=NODE)
+    leaves = np.zeros(max(n, 1), dtype=TRIANGLE_PAIR)
+    codes, idx = np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.uint32)
+    aabb = np.zeros(6, np.int32)
+    lib().ora_build(_p(t), n, _p(nodes), _p(leaves), _p(codes), _p(idx), _p(aabb))
+    return dict(nodes=nodes, leaves=leaves[:n], codes=codes[:n], indices=idx[:n], aabb=aabb, n=n)
+
+
+def count_nodes(nodes: np.ndarray, root: int, count: int) -> tuple:
+    out = np.zeros(3, np.int32)
+    lib().ora_count_nodes(_p(np.ascontiguousarray(nodes)), root, count, _p(out))
+    return int(out[0]), int(out[1]), int(out[2])
+
+
+def verify_hierarchy(nodes: np.ndarray, root: int, count: int) -> int:
+    return int(lib().ora_verify_hierarchy(_p(np.ascontiguousarray(nodes)), root, count))
+
+
+def trace(leaves, nodes, root, count, camera, w, h, *, render_type=0, attributes=None, materials=None, light=(0, 0, 0),
+          rows=None, spp=1):
+    """TraceRays on the CPU.  Returns (rgba8 [h, w, 4] uint8, counters [box, tri, max_stack])."""
+    rgba = np.zeros((h, w, 4), np.uint8)
+    counters = np.zeros(3, np.uint64)
+    y0, y1 = (0, h) if rows is None else rows
+    lt = np.asarray(light, np.float32)
+    cam = np.ascontiguousarray(camera)
+    nm = 0 if materials is None else materials.shape[0]
+    rc = lib().ora_trace(_p(np.ascontiguousarray(leaves)), _p(np.ascontiguousarray(nodes)), root, count,
+                         _p(None if attributes is None else np.ascontiguousarray(attributes)),
+                         _p(None if materials is None else np.ascontiguousarray(materials)), nm, _p(cam), _p(lt),
+                         render_type, _p(rgba), w, h, y0, y1, spp, _p(counters))
+    if rc != 0:
+        raise ValueError(f"oracle: unsupported render type {render_type}")
+    return rgba, counters
+
+
+# ---------------------------------------------------------------- the reference's own checker (oracle/_ref)
+class _HierarchyStats(ctypes.Structure):  # Utilities.h:3-7
+    _fields_ = [("numNodes", ctypes.c_int), ("numLeafNodes", ctypes.c_int), ("numTreeNodes", ctypes.c_int)]
+
+
+_ref = None
+
+
+def ref_available() -> bool:
+    return os.path.exists(REF_PATH)
+
+
+def _reflib():
+    global _ref
+    if _ref is None:
+        R = ctypes.CDLL(REF_PATH)
+        R.count = getattr(R, "_Z10CountNodesP4Nodejj")           # HierarchyStats CountNodes(Node*, unsigned, unsigned)
+        R.count.restype = _HierarchyStats
+        R.count.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]
+        R.verify = getattr(R, "_Z15VerifyHierarchyP4Nodejj")    # void VerifyHierarchy(Node*, unsigned, unsigned)
+        R.verify.restype = None
+        R.verify.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]
+        _ref = R
+    return _ref
+
+
+def ref_count_nodes(nodes: np.ndarray, root: int, count: int) -> tuple:
+    """Reference CountNodes (Utilities.cpp:32-44), the compiled reference code itself."""
+    s = _reflib().count(_p(np.ascontiguousarray(nodes)), root, count)
+    return s.numNodes, s.numLeafNodes, s.numTreeNodes
+
+
+def ref_verify_hierarchy(nodes: np.ndarray, root: int, count: int) -> str:
+    """Reference VerifyHierarchy (Utilities.cpp:77-83).  It reports by printing to stderr; returns what it printed
+    ('' = hierarchy valid)."""
+    import sys
+    R = _reflib()
+    a = np.ascontiguousarray(nodes)
+    sys.stderr.flush()
+    libc = ctypes.CDLL(None)
+    with tempfile.TemporaryFile(mode="w+b") as tmp:
+        saved = os.dup(2)
+        try:
+            os.dup2(tmp.fileno(), 2)
+            R.verify(_p(a), root, count)
+            libc.fflush(None)
+        finally:
+            os.dup2(saved, 2)
+            os.close(saved)
+        tmp.seek(0)
+        return tmp.read().decode(errors="replace")

@@ -1,0 +1,668 @@
+/*
+ * rt_oracle.c -- see rt_oracle.h.  TEST INFRASTRUCTURE ONLY (checker + timed CPU baseline).
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math -fopenmp -fPIC -shared (oracle/Makefile).
+ * All file:line citations are relative to /root/reference/src.
+ */
+#include "rt_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static int g_threads = 1;
+void ora_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int ora_get_threads(void) { return g_threads; }
+
+/* ------------------------------------------------------------------ float3 helpers
+ * helper_math.h: componentwise + - * / (:990-1013), dot (:1266) = x*x + y*y + z*z left to right,
+ * cross (:1444), normalize = v * rsqrtf(dot(v,v)) (:1318) with rsqrtf := 1/sqrtf (:50). */
+static inline ora_f3 f3(float x, float y, float z) { ora_f3 r = {x, y, z}; return r; }
+static inline ora_f3 add3(ora_f3 a, ora_f3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline ora_f3 sub3(ora_f3 a, ora_f3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline ora_f3 mul3(ora_f3 a, ora_f3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline ora_f3 div3(ora_f3 a, ora_f3 b) { return f3(a.x / b.x, a.y / b.y, a.z / b.z); }
+static inline ora_f3 scale3(ora_f3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+static inline ora_f3 min3(ora_f3 a, ora_f3 b) { return f3(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)); }
+static inline ora_f3 max3(ora_f3 a, ora_f3 b) { return f3(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)); }
+static inline float dot3(ora_f3 a, ora_f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline ora_f3 cross3(ora_f3 a, ora_f3 b)
+{
+    return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+static inline ora_f3 normalize3(ora_f3 v)
+{
+    float inv_len = 1.0f / sqrtf(dot3(v, v));
+    return scale3(v, inv_len);
+}
+static inline float clampf(float f, float a, float b) { return fmaxf(a, fminf(f, b)); } /* helper_math.h:1161 */
+
+/* ------------------------------------------------------------------ DeviceUtils.cuh:3-13 */
+int32_t ora_float_to_ordered_int(float f)
+{
+    int32_t i;
+    memcpy(&i, &f, 4);
+    return (i >= 0) ? i : i ^ 0x7FFFFFFF;
+}
+float ora_ordered_int_to_float(int32_t i)
+{
+    int32_t j = (i >= 0) ? i : i ^ 0x7FFFFFFF;
+    float f;
+    memcpy(&f, &j, 4);
+    return f;
+}
+
+/* ------------------------------------------------------------------ Multiblock.cu:104-114
+ * CalculateSceneAabb: per triangle box, folded with integer atomicMin/Max on the ordered-int
+ * encoding (AtomicConvertCombine :34-42) into a box initialised to the ordered-int "empty"
+ * {0x7f7fffff x3, 0x80800000 x3} (BuildWrapper.cu:288-289).  Order independent.  The fold is done
+ * entirely in the ordered-int domain here (differs from per-triangle fminf only in which of -0/+0
+ * survives inside one triangle; the integer order -0 < +0 is what the reference's atomics use). */
+void ora_scene_aabb(const ora_triangle* tris, uint32_t n, int32_t out[6])
+{
+    int32_t lo[3] = {0x7f7fffff, 0x7f7fffff, 0x7f7fffff};
+    int32_t hi[3] = {(int32_t)0x80800000, (int32_t)0x80800000, (int32_t)0x80800000};
+    const float* f = (const float*)tris;
+    for (size_t i = 0; i < (size_t)n * 9; i++) {
+        int32_t v = ora_float_to_ordered_int(f[i]);
+        int a = (int)(i % 3);
+        if (v < lo[a]) lo[a] = v;
+        if (v > hi[a]) hi[a] = v;
+    }
+    out[0] = lo[0]; out[1] = lo[1]; out[2] = lo[2];
+    out[3] = hi[0]; out[4] = hi[1]; out[5] = hi[2];
+}
+
+/* ------------------------------------------------------------------ BottomUpBuilder.cu:12-32 */
+static inline uint32_t expand_bits(uint32_t v)
+{
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+static inline uint32_t morton3d(float x, float y, float z)
+{
+    x = fminf(fmaxf(x * 1024.0f, 0.0f), 1023.0f);
+    y = fminf(fmaxf(y * 1024.0f, 0.0f), 1023.0f);
+    z = fminf(fmaxf(z * 1024.0f, 0.0f), 1023.0f);
+    uint32_t xx = expand_bits((uint32_t)x);
+    uint32_t yy = expand_bits((uint32_t)y);
+    uint32_t zz = expand_bits((uint32_t)z);
+    return xx * 4 + yy * 2 + zz;
+}
+
+/* BottomUpBuilder.cu:98-115 GenerateMortonCodes */
+void ora_morton_codes(const ora_triangle* tris, uint32_t n, const int32_t aabb[6], uint32_t* codes,
+                      uint32_t* values)
+{
+    ora_f3 smin = f3(ora_ordered_int_to_float(aabb[0]), ora_ordered_int_to_float(aabb[1]),
+                     ora_ordered_int_to_float(aabb[2]));
+    ora_f3 smax = f3(ora_ordered_int_to_float(aabb[3]), ora_ordered_int_to_float(aabb[4]),
+                     ora_ordered_int_to_float(aabb[5]));
+    ora_f3 ext = sub3(smax, smin);
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; i++) {
+        ora_f3 c = add3(add3(tris[i].v0, tris[i].v1), tris[i].v2);
+        c = f3(c.x / 3.0f, c.y / 3.0f, c.z / 3.0f);
+        c = div3(sub3(c, smin), ext);
+        c = f3(clampf(c.x, 0.0f, 1.0f), clampf(c.y, 0.0f, 1.0f), clampf(c.z, 0.0f, 1.0f));
+        codes[i] = morton3d(c.x, c.y, c.z);
+        values[i] = (uint32_t)i;
+    }
+}
+
+/* ------------------------------------------------------------------ RadixSort.cu:171-225
+ * Contract: 4 LSD passes x 8 bits, each a stable counting scatter (stable because Distribute ranks
+ * equal digits in input order, :153-158); ping-pong keys<->tmp so the result lands back in keys/vals.
+ * Parallel form: per-thread chunk histograms, (digit, chunk)-ordered exclusive scan -- the same
+ * [digit][segment] table the reference scans (:196-201) with chunks in place of its 128 segments. */
+void ora_radix_sort(uint32_t* keys, uint32_t* vals, uint32_t* tk, uint32_t* tv, uint32_t n)
+{
+    int T = g_threads;
+    uint32_t* hist = (uint32_t*)malloc((size_t)T * 256 * sizeof(uint32_t));
+    uint32_t *sk = keys, *sv = vals, *dk = tk, *dv = tv;
+    for (int pass = 0; pass < 4; pass++) {
+        int shift = pass * 8;
+        memset(hist, 0, (size_t)T * 256 * sizeof(uint32_t));
+#pragma omp parallel num_threads(T)
+        {
+#ifdef _OPENMP
+            int t = omp_get_thread_num();
+#else
+            int t = 0;
+#endif
+            size_t b = (size_t)n * t / T, e = (size_t)n * (t + 1) / T;
+            uint32_t* h = hist + (size_t)t * 256;
+            for (size_t i = b; i < e; i++) h[(sk[i] >> shift) & 0xFF]++;
+#pragma omp barrier
+#pragma omp single
+            {
+                uint32_t sum = 0;
+                for (int d = 0; d < 256; d++)
+                    for (int c = 0; c < T; c++) {
+                        uint32_t v = hist[(size_t)c * 256 + d];
+                        hist[(size_t)c * 256 + d] = sum;
+                        sum += v;
+                    }
+            }
+            for (size_t i = b; i < e; i++) {
+                uint32_t k = sk[i];
+                uint32_t pos = h[(k >> shift) & 0xFF]++;
+                dk[pos] = k;
+                dv[pos] = sv[i];
+            }
+        }
+        uint32_t* x;
+        x = sk; sk = dk; dk = x;
+        x = sv; sv = dv; dv = x;
+    }
+    free(hist);
+}
+
+/* ------------------------------------------------------------------ BottomUpBuilder.cu:34-38 */
+static inline int clz32(uint32_t x) { return x ? __builtin_clz(x) : 32; }
+static inline int cpl(const uint32_t* codes, uint32_t i, uint32_t j)
+{
+    return codes[i] == codes[j] ? 32 + clz32(i ^ j) : clz32(codes[i] ^ codes[j]);
+}
+static inline int sign_i(int a) { return a >= 0 ? 1 : -1; }
+
+/* BottomUpBuilder.cu:42-68.  `i + lmax*d < count` is an int-vs-unsigned compare in the reference;
+ * it is only evaluated after `>= 0` passed, so it equals the plain bounds test used here. */
+static void determine_range(const uint32_t* codes, uint32_t count, int i, int* first, int* last)
+{
+    if (i == 0) { *first = 0; *last = (int)count - 1; return; }
+    int d = sign_i(cpl(codes, i, i + 1) - cpl(codes, i, i - 1));
+    int cpl_min = cpl(codes, i, i - d);
+    int64_t lmax = 2;
+    while ((i + lmax * d) >= 0 && (i + lmax * d) < (int64_t)count && cpl(codes, i, (uint32_t)(i + lmax * d)) > cpl_min)
+        lmax *= 2;
+    int64_t l = 0;
+    for (int64_t t = lmax >> 1; t; t >>= 1) {
+        if ((i + (l + t) * d) >= 0 && (i + (l + t) * d) < (int64_t)count &&
+            cpl(codes, i, (uint32_t)(i + (l + t) * d)) > cpl_min)
+            l += t;
+    }
+    int j = (int)(i + l * d);
+    if (d > 0) { *first = i; *last = j; } else { *first = j; *last = i; }
+}
+
+/* BottomUpBuilder.cu:70-96 */
+static int find_split(const uint32_t* codes, int first, int last)
+{
+    int common_prefix = cpl(codes, first, last);
+    int split = first;
+    int step = last - first;
+    do {
+        step = (step + 1) >> 1;
+        int new_split = split + step;
+        if (new_split < last) {
+            int split_prefix = cpl(codes, first, new_split);
+            if (split_prefix > common_prefix) split = new_split;
+        }
+    } while (step > 1);
+    return split;
+}
+
+#define NODE_PARENT_MASK 0x1FFFFFFFu
+static inline void set_child_type(ora_node* nd, uint32_t child, uint32_t type) { nd->w28 = (child & NODE_PARENT_MASK) | (type << 29); }
+static inline void set_parent(ora_node* nd, uint32_t parent) { nd->w12 = (nd->w12 & ~NODE_PARENT_MASK) | (parent & NODE_PARENT_MASK); }
+static inline void set_count(ora_node* nd, uint32_t count) { nd->w12 = (nd->w12 & NODE_PARENT_MASK) | (count << 29); }
+
+/* BottomUpBuilder.cu:167-215 GenerateHierarchy.  Parallel over internal nodes; every 32-bit word is
+ * written by exactly one node (child/type word by the owner, parent word of a pair by its parent;
+ * count bits are written later by ora_generate_aabbs) so threads never share a word at the same time:
+ * the parent word write below is a read-modify-write of w12, whose count bits nobody touches in this
+ * phase. */
+void ora_generate_hierarchy(ora_node* nodes, uint32_t* leaf_indices, const uint32_t* codes, uint32_t L)
+{
+    if (L < 2) return;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int64_t ii = 0; ii < (int64_t)L - 1; ii++) {
+        uint32_t idx = (uint32_t)ii;
+        int first, last;
+        determine_range(codes, L, (int)idx, &first, &last);
+        int split = find_split(codes, first, last);
+        uint32_t child_a = (split == first) ? (uint32_t)split : (uint32_t)split * 2;
+        uint32_t type_a = (split == first) ? ORA_TYPE_TRI : ORA_TYPE_BOX;
+        uint32_t child_b = (split + 1 == last) ? (uint32_t)split + 1 : ((uint32_t)split + 1) * 2;
+        uint32_t type_b = (split + 1 == last) ? ORA_TYPE_TRI : ORA_TYPE_BOX;
+        set_child_type(&nodes[idx * 2 + 0], child_a, type_a);
+        set_child_type(&nodes[idx * 2 + 1], child_b, type_b);
+        if (type_a == ORA_TYPE_BOX) {
+            set_parent(&nodes[child_a + 0], idx << 1);
+            set_parent(&nodes[child_a + 1], idx << 1);
+        } else
+            leaf_indices[split] = idx << 1;
+        if (type_b == ORA_TYPE_BOX) {
+            set_parent(&nodes[child_b + 0], (idx << 1) + 1);
+            set_parent(&nodes[child_b + 1], (idx << 1) + 1);
+        } else
+            leaf_indices[split + 1] = (idx << 1) + 1;
+    }
+}
+
+/* BottomUpBuilder.cu:287-312 GenerateTriangles (non-pair branch).  Q1: the reference leaves
+ * primitive_id_0/1, rotations, pad3 uninitialised; defined here as id = original triangle index,
+ * everything else 0.  Q2: the reference's read of triangle index+1 is not reproduced. */
+void ora_generate_triangles(const uint32_t* sorted_indices, const ora_triangle* tris, ora_triangle_pair* out, uint32_t L)
+{
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int64_t g = 0; g < (int64_t)L; g++) {
+        uint32_t index = sorted_indices[g] & 0x7FFFFFFFu;
+        ora_triangle_pair r;
+        memset(&r, 0, sizeof r);
+        r.v0 = tris[index].v0;
+        r.v1 = tris[index].v1;
+        r.v2 = tris[index].v2;
+        r.v3 = r.v2;
+        r.primitive_id_0 = index;
+        out[g] = r;
+    }
+}
+
+/* BottomUpBuilder.cu:247-285 GenerateAABBs + UpdateAABB (:217-233).  locks must be zero on entry
+ * (BuildWrapper.cu:338).  f3min/f3max are min()/max() on floats = fminf/fmaxf on the device. */
+void ora_generate_aabbs(ora_node* nodes, const uint32_t* leaf_indices, const uint32_t* sorted_indices,
+                        uint32_t* locks, const ora_triangle_pair* leaves, uint32_t L)
+{
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int64_t g = 0; g < (int64_t)L; g++) {
+        uint32_t leaf_index = leaf_indices[g];
+        int is_pair = (int)(sorted_indices[g] >> 31);
+        ora_f3 bmin = min3(min3(leaves[g].v0, leaves[g].v1), leaves[g].v2);
+        ora_f3 bmax = max3(max3(leaves[g].v0, leaves[g].v1), leaves[g].v2);
+        if (is_pair) {
+            bmin = min3(bmin, leaves[g].v3);
+            bmax = max3(bmax, leaves[g].v3);
+        }
+        nodes[leaf_index].min = bmin;
+        nodes[leaf_index].max = bmax;
+        set_count(&nodes[leaf_index], 1);
+        uint32_t index = leaf_index;
+        while (index > 1) {
+            /* first arrival at the pair stops, second continues (atomicAdd(&locks[index>>1],1)) */
+            uint32_t old = __atomic_fetch_add(&locks[index >> 1], 1u, __ATOMIC_SEQ_CST);
+            if (!old) break;
+            uint32_t p = nodes[index].w12 & NODE_PARENT_MASK;
+            if ((nodes[p].w28 >> 29) == ORA_TYPE_BOX) {
+                uint32_t child = nodes[p].w28 & NODE_PARENT_MASK;
+                uint32_t right = index & 1;
+                bmin = min3(bmin, nodes[child + 1 - right].min);
+                bmax = max3(bmax, nodes[child + 1 - right].max);
+                nodes[p].min = bmin;
+                nodes[p].max = bmax;
+            }
+            set_count(&nodes[p], 2);
+            index = p;
+        }
+    }
+}
+
+/* BuildWrapper.cu:253-348 RunBottomUpBuild (pairs off, hybrid off).  Differences, all documented in
+ * nodes are zeroed first (Q3: the reference never initialises nodes_out, so
+ * parent of slots 0/1 and every padding bit is defined as 0 here); n < 2 is special-cased (Q8):
+ * n == 1 -> slot 0 is the leaf descriptor, slot 1 stays type None; n == 0 -> both None. */
+void ora_build(const ora_triangle* tris, uint32_t n, ora_node* nodes, ora_triangle_pair* leaves,
+               uint32_t* codes_sorted, uint32_t* indices_sorted, int32_t* aabb_ordered)
+{
+    uint32_t slots = 2 * (n > 1 ? n - 1 : 1);
+    memset(nodes, 0, (size_t)slots * sizeof(ora_node));
+    int32_t aabb[6];
+    ora_scene_aabb(tris, n, aabb);
+    if (aabb_ordered) memcpy(aabb_ordered, aabb, sizeof aabb);
+    if (n == 0) return;
+
+    uint32_t* codes = (uint32_t*)malloc((size_t)n * 4);
+    uint32_t* vals = (uint32_t*)malloc((size_t)n * 4);
+    uint32_t* t1 = (uint32_t*)calloc((size_t)n, 4); /* "locks"        used as sort temp (BuildWrapper.cu:330-332) */
+    uint32_t* t2 = (uint32_t*)calloc((size_t)n, 4); /* "leaf_indices" used as sort temp */
+    ora_morton_codes(tris, n, aabb, codes, vals);
+    ora_radix_sort(codes, vals, t1, t2, n);
+    if (codes_sorted) memcpy(codes_sorted, codes, (size_t)n * 4);
+    if (indices_sorted) memcpy(indices_sorted, vals, (size_t)n * 4);
+
+    ora_generate_triangles(vals, tris, leaves, n);
+    if (n == 1) {
+        ora_f3 bmin = min3(min3(leaves[0].v0, leaves[0].v1), leaves[0].v2);
+        ora_f3 bmax = max3(max3(leaves[0].v0, leaves[0].v1), leaves[0].v2);
+        nodes[0].min = bmin;
+        nodes[0].max = bmax;
+        nodes[0].w12 = 1u << 29;
+        nodes[0].w28 = 0u | ((uint32_t)ORA_TYPE_TRI << 29);
+    } else {
+        ora_generate_hierarchy(nodes, t2, codes, n);
+        memset(t1, 0, (size_t)n * 4);
+        ora_generate_aabbs(nodes, t2, vals, t1, leaves, n);
+    }
+    free(codes); free(vals); free(t1); free(t2);
+}
+
+/* ------------------------------------------------------------------ Utilities.cpp:8-44
+ * (recursion restated with an explicit stack so deep trees cannot overflow the C stack) */
+void ora_count_nodes(const ora_node* nodes, uint32_t root, uint32_t count, int32_t out[3])
+{
+    int32_t num_nodes = 0, num_leaf = 0, num_tree = 0;
+    size_t cap = 1024, sp = 0;
+    uint32_t* st = (uint32_t*)malloc(cap * 4);
+    for (uint32_t i = count; i-- > 0;)
+        if ((nodes[root + i].w28 >> 29) == ORA_TYPE_BOX) st[sp++] = root + i;
+    while (sp) {
+        uint32_t idx = st[--sp];
+        num_nodes++;
+        uint32_t type = nodes[idx].w28 >> 29;
+        if (type == ORA_TYPE_TRI) num_leaf++;
+        else if (type == ORA_TYPE_BOX) {
+            num_tree++;
+            uint32_t c = nodes[idx].w28 & NODE_PARENT_MASK, k = nodes[idx].w12 >> 29;
+            if (sp + k + 1 > cap) { cap *= 2; st = (uint32_t*)realloc(st, cap * 4); }
+            for (uint32_t i = k; i-- > 0;) st[sp++] = c + i;
+        }
+    }
+    free(st);
+    out[0] = num_nodes; out[1] = num_leaf; out[2] = num_tree;
+}
+
+/* Utilities.cpp:46-83: a Box slot's min/max must EXACTLY equal the union of its `count` children;
+ * on failure the reference prints and does not descend.  Returns the number of failures. */
+int ora_verify_hierarchy(const ora_node* nodes, uint32_t root, uint32_t count)
+{
+    int errors = 0;
+    size_t cap = 1024, sp = 0;
+    uint32_t* st = (uint32_t*)malloc(cap * 4);
+    for (uint32_t i = 0; i < count; i++)
+        if ((nodes[root + i].w28 >> 29) == ORA_TYPE_BOX) st[sp++] = root + i;
+    while (sp) {
+        uint32_t idx = st[--sp];
+        if ((nodes[idx].w28 >> 29) != ORA_TYPE_BOX) continue;
+        uint32_t c = nodes[idx].w28 & NODE_PARENT_MASK, k = nodes[idx].w12 >> 29;
+        ora_f3 cmin = f3(3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f);
+        ora_f3 cmax = f3(-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f);
+        for (uint32_t i = 0; i < k; i++) {
+            cmin = min3(cmin, nodes[c + i].min);
+            cmax = max3(cmax, nodes[c + i].max);
+        }
+        if (nodes[idx].min.x != cmin.x || nodes[idx].min.y != cmin.y || nodes[idx].min.z != cmin.z ||
+            nodes[idx].max.x != cmax.x || nodes[idx].max.y != cmax.y || nodes[idx].max.z != cmax.z) {
+            errors++;
+            continue;
+        }
+        if (sp + k + 1 > cap) { cap *= 2; st = (uint32_t*)realloc(st, cap * 4); }
+        for (uint32_t i = 0; i < k; i++) st[sp++] = c + i;
+    }
+    free(st);
+    return errors;
+}
+
+/* ================================================================== Tracer.cu */
+typedef struct { ora_f3 origin; float tmin; ora_f3 direction; float tmax; } ray_t;       /* Tracer.cuh:9-14 */
+typedef struct { uint32_t primitive_id, tri_id; float bu, bv; } ray_result_t;            /* Tracer.cu:4-8   */
+typedef struct { uint32_t box_tests, tri_tests, max_stack; } stats_t;                    /* Tracer.cuh:4-7  */
+
+/* Tracer.cu:187-200 IntersectRayAabb */
+static inline int intersect_ray_aabb(const ora_node* node, const ray_t* ray, float* distance)
+{
+    ora_f3 inv_dir = f3(1.0f / ray->direction.x, 1.0f / ray->direction.y, 1.0f / ray->direction.z);
+    ora_f3 t1 = mul3(sub3(node->min, ray->origin), inv_dir);
+    ora_f3 t2 = mul3(sub3(node->max, ray->origin), inv_dir);
+    ora_f3 tmin = min3(t1, t2);
+    ora_f3 tmax = max3(t1, t2);
+    float front = fmaxf(fmaxf(tmin.x, tmin.y), tmin.z);
+    float back = fminf(fminf(tmax.x, tmax.y), tmax.z);
+    *distance = front;
+    return back >= front && front <= ray->tmax && back >= ray->tmin;
+}
+
+/* Tracer.cu:256-291 IntersectRayTriangle */
+static inline int intersect_ray_triangle(ora_f3 v0, ora_f3 v1, ora_f3 v2, ray_t* ray, ray_result_t* rr,
+                                         uint32_t tri_id, uint32_t prim_id)
+{
+    const float epsilon = 0.000000001f;
+    ora_f3 edge1 = sub3(v1, v0);
+    ora_f3 edge2 = sub3(v2, v0);
+    ora_f3 h = cross3(ray->direction, edge2);
+    float a = dot3(edge1, h);
+    if (a > -epsilon && a < epsilon) return 0;
+    float f = 1.0f / a;
+    ora_f3 s = sub3(ray->origin, v0);
+    float u = f * dot3(s, h);
+    if (u < 0.0f || u > 1.0f) return 0;
+    ora_f3 q = cross3(s, edge1);
+    float v = f * dot3(ray->direction, q);
+    if (v < 0.0f || (u + v) > 1.0f) return 0;
+    float t = f * dot3(edge2, q);
+    if (t < ray->tmin || t > ray->tmax) return 0;
+    ray->tmax = t;
+    rr->primitive_id = prim_id;
+    rr->tri_id = tri_id;
+    rr->bu = u;
+    rr->bv = v;
+    return 1;
+}
+
+/* Tracer.cu:293-306 IntersectRayTrianglePair */
+static inline int intersect_ray_triangle_pair(const ora_triangle_pair* tp, ray_t* ray, ray_result_t* rr,
+                                              uint32_t pair_id, int pair)
+{
+    int hit_a = intersect_ray_triangle(tp->v0, tp->v1, tp->v2, ray, rr, pair_id << 1, tp->primitive_id_0);
+    int hit_b = pair ? intersect_ray_triangle(tp->v2, tp->v1, tp->v3, ray, rr, (pair_id << 1) + 1, tp->primitive_id_1) : 0;
+    return hit_a || hit_b;
+}
+
+/* Tracer.cu:308-374 TraceRay.  The reference prints "stack overflow" when stack_size reaches 64 and
+ * then writes out of bounds; here a push at 64 is dropped (cannot happen on a binary LBVH, SURVEY A). */
+typedef struct { uint32_t index, count; } stack_entry_t;
+#define PUSH(e) do { if (sp < 64) stack[sp++] = (e); if (sp > stats->max_stack) stats->max_stack = sp; } while (0)
+static int trace_ray(const ora_triangle_pair* leaves, const ora_node* nodes, uint32_t root, uint32_t count,
+                     ray_t* ray, ray_result_t* rr, stats_t* stats)
+{
+    int tri_hit = 0;
+    unsigned sp = 1;
+    stack_entry_t stack[64];
+    stack[0].index = root;
+    stack[0].count = count;
+    while (sp) {
+        stack_entry_t entry = stack[--sp];
+        unsigned num_hits = 0;
+        stack_entry_t child_buffer = {0, 0};
+        float child_dist = 0.0f;
+        for (unsigned i = 0; i < entry.count; i++) {
+            const ora_node* node = &nodes[entry.index + i];
+            uint32_t type = node->w28 >> 29, child = node->w28 & NODE_PARENT_MASK, ncount = node->w12 >> 29;
+            if (type == ORA_TYPE_NONE) continue;
+            float dist;
+            int hit = intersect_ray_aabb(node, ray, &dist);
+            int is_leaf = type == ORA_TYPE_TRI;
+            stats->box_tests++;
+            if (hit && is_leaf) {
+                stats->tri_tests++;
+                int hit_tri = intersect_ray_triangle_pair(&leaves[child], ray, rr, child, ncount > 0);
+                tri_hit |= hit_tri;
+            } else if (hit && num_hits == 0) {
+                child_buffer.index = child;
+                child_buffer.count = ncount;
+                child_dist = dist;
+                num_hits++;
+            } else if (hit) {
+                if (dist < child_dist || (dist == child_dist && child > child_buffer.index)) {
+                    stack_entry_t tmp = child_buffer;
+                    child_buffer.index = child;
+                    child_buffer.count = ncount;
+                    child_dist = dist;
+                    PUSH(tmp);
+                } else {
+                    stack_entry_t e = {child, ncount};
+                    PUSH(e);
+                }
+            }
+        }
+        if (num_hits > 0) PUSH(child_buffer);
+    }
+    return tri_hit;
+}
+
+/* Tracer.cu:57-82 RotateAttributes */
+static ora_attributes rotate_attributes(const ora_attributes* in, int second_tri, uint16_t rx, uint16_t ry)
+{
+    uint16_t r = second_tri ? ry : rx;
+    ora_attributes o = *in;
+    if (r == 1) {
+        o.normal[0] = in->normal[2]; o.normal[1] = in->normal[0]; o.normal[2] = in->normal[1];
+        o.uv[0][0] = in->uv[2][0]; o.uv[0][1] = in->uv[2][1];
+        o.uv[1][0] = in->uv[0][0]; o.uv[1][1] = in->uv[0][1];
+        o.uv[2][0] = in->uv[1][0]; o.uv[2][1] = in->uv[1][1];
+    } else if (r == 2) {
+        o.normal[0] = in->normal[1]; o.normal[1] = in->normal[2]; o.normal[2] = in->normal[0];
+        o.uv[0][0] = in->uv[1][0]; o.uv[0][1] = in->uv[1][1];
+        o.uv[1][0] = in->uv[2][0]; o.uv[1][1] = in->uv[2][1];
+        o.uv[2][0] = in->uv[0][0]; o.uv[2][1] = in->uv[0][1];
+    }
+    return o;
+}
+
+/* Tracer.cu:15-41 HsvToRgb -> float rgb in [0,255] before the uchar truncation */
+static ora_f3 hsv_to_rgb255(float h, float s, float v)
+{
+    h = clampf(h, 0.f, 1.f) * 360.0f;
+    s = clampf(s, 0.f, 1.f);
+    v = clampf(v, 0.f, 1.f);
+    float c = s * v;
+    float x = c * (1 - fabsf(((int)h % 120) / 60.0f - 1));
+    float m = v - c;
+    ora_f3 rgb;
+    if (h >= 0 && h < 60) rgb = f3(c, x, 0);
+    else if (h >= 60 && h < 120) rgb = f3(x, c, 0);
+    else if (h >= 120 && h < 180) rgb = f3(0, c, x);
+    else if (h >= 180 && h < 240) rgb = f3(0, x, c);
+    else if (h >= 240 && h < 300) rgb = f3(x, 0, c);
+    else rgb = f3(c, 0, x);
+    return f3((rgb.x + m) * 255, (rgb.y + m) * 255, (rgb.z + m) * 255);
+}
+
+/* Tracer.cu:376-469 AmbientShader with use_textures = use_shadows = use_bump = false (kDiffuse, :536-541).
+ * `max(dot, 0.0)` and pow() are evaluated in double on the device (float/double overloads), the product
+ * `1.0f * pow(...)` is narrowed to float by operator*(float, float3) -- restated literally. */
+static ora_f3 ambient_shader255(const ray_t* ray, const ray_result_t* rr, const ora_material* mat,
+                                const ora_attributes* at, const float light[3])
+{
+    ora_f3 light_colour = f3(1.0f, 0.9f, 0.8f);
+    ora_f3 light_pos = f3(light[0], light[1], light[2]);
+    ora_f3 hit_pos = add3(ray->origin, scale3(ray->direction, ray->tmax));
+    /* InterpolateNormals (:50-56) */
+    float w0 = 1 - rr->bu - rr->bv;
+    ora_f3 normal = add3(add3(scale3(at->normal[0], w0), scale3(at->normal[1], rr->bu)), scale3(at->normal[2], rr->bv));
+    ora_f3 light_dir = normalize3(sub3(light_pos, hit_pos));
+    ora_f3 ambient = scale3(light_colour, 0.2f);
+    ora_f3 diffuse = scale3(light_colour, 1.0f * fmaxf(dot3(normal, light_dir), 0.0f));
+    ora_f3 neg_l = f3(-light_dir.x, -light_dir.y, -light_dir.z);
+    /* reflect(i, n) = i - 2.0f * n * dot(n, i)   (helper_math.h:1435-1438) */
+    ora_f3 refl = sub3(neg_l, scale3(scale3(normal, 2.0f), dot3(normal, neg_l)));
+    ora_f3 neg_d = f3(-ray->direction.x, -ray->direction.y, -ray->direction.z);
+    double sp_base = fmax((double)dot3(neg_d, refl), 0.0);
+    float sp = (float)(1.0f * pow(sp_base, (double)mat->specular_exp));
+    ora_f3 specular = scale3(light_colour, sp);
+    ora_f3 colour = add3(add3(mul3(diffuse, mat->diffuse), mul3(ambient, mat->ambient)), mul3(specular, mat->specular));
+    colour = f3(clampf(colour.x, 0.0f, 1.0f), clampf(colour.y, 0.0f, 1.0f), clampf(colour.z, 0.0f, 1.0f));
+    return f3(colour.x * 255, colour.y * 255, colour.z * 255);
+}
+
+/* Tracer.cu:471-595 TraceRays.  One pixel; returns the float colour (0..255 per channel, before the
+ * uchar truncation of :512-514 / :468) so that spp>1 can average. */
+static ora_f3 shade_pixel(const ora_triangle_pair* leaves, const ora_node* nodes, uint32_t root, uint32_t count,
+                          const ora_attributes* attributes, const ora_material* materials, uint32_t num_materials,
+                          const ora_camera* cam, const float light[3], int render_type, uint32_t x, uint32_t y,
+                          uint32_t w, uint32_t h, float ox, float oy, stats_t* stats)
+{
+    float cx = (float)x, cy = (float)y;
+    float ndcx = 2 * ((cx + ox) / (float)w) - 1;
+    float ndcy = 2 * ((cy + oy) / (float)h) - 1;
+    ora_f3 p = add3(add3(scale3(cam->u, ndcx), scale3(cam->v, ndcy)), scale3(cam->w, 1.0f));
+    float max_depth = cam->max_depth;
+    ray_t ray;
+    ray.direction = normalize3(p);
+    ray.origin = cam->position;
+    ray.tmin = 0.00001f;
+    ray.tmax = max_depth;
+    ray_result_t rr = {0, 0, 0.f, 0.f};
+    stats_t st = {0, 0, 0};
+    int hit = trace_ray(leaves, nodes, root, count, &ray, &rr, &st);
+    float depth = hit ? ray.tmax : 0.0f;
+    stats->box_tests += st.box_tests;
+    stats->tri_tests += st.tri_tests;
+    if (st.max_stack > stats->max_stack) stats->max_stack = st.max_stack;
+
+    switch (render_type) {
+    case ORA_DEPTH: {
+        float g = fminf(1.0f, depth / max_depth) * 255;
+        return f3(g, g, g);
+    }
+    case ORA_BOXTESTS: {
+        float g = fminf(st.box_tests / 180.0f, 1.0f) * 255;
+        return f3(0, g, g);
+    }
+    case ORA_TRITESTS: {
+        float g = fminf(st.tri_tests / 32.0f, 1.0f);
+        return f3(g * 100, g * 255, g * 100);
+    }
+    default: break;
+    }
+    if (!hit) return f3(0, 0, 0);
+    int second_tri = rr.tri_id & 1;
+    const ora_triangle_pair* pair = &leaves[rr.tri_id >> 1];
+    ora_attributes at = rotate_attributes(&attributes[rr.primitive_id], second_tri, pair->rot_x, pair->rot_y);
+    if (render_type == ORA_MATERIALID)
+        return hsv_to_rgb255((float)at.material_id / num_materials, 1.0f, 1.0f);
+    /* ORA_DIFFUSE */
+    return ambient_shader255(&ray, &rr, &materials[at.material_id], &at, light);
+}
+
+int ora_trace(const ora_triangle_pair* leaves, const ora_node* nodes, uint32_t root, uint32_t count,
+              const ora_attributes* attributes, const ora_material* materials, uint32_t num_materials,
+              const ora_camera* camera, const float light[3], int render_type, uint8_t* rgba8, uint32_t w,
+              uint32_t h, uint32_t y0, uint32_t y1, uint32_t spp, uint64_t* counters)
+{
+    if (!(render_type == ORA_DEPTH || render_type == ORA_BOXTESTS || render_type == ORA_TRITESTS ||
+          render_type == ORA_MATERIALID || render_type == ORA_DIFFUSE))
+        return -1;
+    if (spp < 1) spp = 1;
+    uint64_t box = 0, tri = 0;
+    uint32_t maxst = 0;
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 4) reduction(+ : box, tri) reduction(max : maxst)
+    for (int64_t yy = y0; yy < (int64_t)y1; yy++) {
+        uint32_t y = (uint32_t)yy;
+        for (uint32_t x = 0; x < w; x++) {
+            stats_t st = {0, 0, 0};
+            ora_f3 c;
+            if (spp == 1) {
+                c = shade_pixel(leaves, nodes, root, count, attributes, materials, num_materials, camera, light,
+                                render_type, x, y, w, h, 0.5f, 0.5f, &st);
+            } else {
+                ora_f3 acc = f3(0, 0, 0);
+                for (uint32_t s = 0; s < spp; s++) {
+                    float ox = ((float)(s % 4) + 0.5f) / 4.0f, oy = ((float)((s / 4) % 4) + 0.5f) / 4.0f;
+                    acc = add3(acc, shade_pixel(leaves, nodes, root, count, attributes, materials, num_materials,
+                                                camera, light, render_type, x, y, w, h, ox, oy, &st));
+                }
+                c = f3(acc.x / (float)spp, acc.y / (float)spp, acc.z / (float)spp);
+            }
+            uint8_t* px = rgba8 + ((size_t)y * w + x) * 4;
+            px[0] = (uint8_t)c.x;
+            px[1] = (uint8_t)c.y;
+            px[2] = (uint8_t)c.z;
+            px[3] = 255;
+            box += st.box_tests;
+            tri += st.tri_tests;
+            if (st.max_stack > maxst) maxst = st.max_stack;
+        }
+    }
+    if (counters) {
+        counters[0] += box;
+        counters[1] += tri;
+        if (maxst > counters[2]) counters[2] = maxst;
+    }
+    return 0;
+}

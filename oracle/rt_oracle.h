@@ -1,0 +1,124 @@
+/*
+ * rt_oracle.h -- CPU restatement of the reference's LBVH build + primary-ray tracer.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product path: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library,
+ * and only as the checker / the timed CPU baseline.  The product (gpu-raytracing_amd/) never
+ * links, loads or calls it.
+ *
+ * Every function cites the reference file:line (relative to /root/reference/src) it restates.
+ * Arithmetic is plain C, compiled -O2 -ffp-contract=off, IEEE fminf/fmaxf (minNum/maxNum),
+ * correctly rounded '/' and sqrtf -- the same operation order as the reference's device code
+ * without FMA contraction and with rsqrtf(x) := 1.0f/sqrtf(x).
+ *
+ * PINNING STATUS: the reference ships no tests, fixtures or golden vectors
+ * and its CUDA kernels cannot be built in this image (no nvcc / CUDA device runtime), so the
+ * arithmetic of Morton codes / sort / traversal is "parity unpinned" against reference-held
+ * vectors.  What IS pinned: (1) the reference's own structural check -- VerifyHierarchy and
+ * CountNodes from Utilities.cpp compiled unmodified into oracle/_ref -- is run on the oracle's
+ * (and the GPU's) Node arrays; (2) the node-count identities of SURVEY.md Appendix A.
+ */
+#ifndef RT_ORACLE_H
+#define RT_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float x, y, z; } ora_f3;
+
+/* Common.cuh:199-243  (36 B) */
+typedef struct { ora_f3 v0, v1, v2; } ora_triangle;
+
+/* Common.cuh:152-159  (32 B).  w12 = parent:29 (LSBs) | count:3 ; w28 = child:29 (LSBs) | type:3 */
+typedef struct { ora_f3 min; uint32_t w12; ora_f3 max; uint32_t w28; } ora_node;
+
+/* Common.cuh:161-197  (64 B) */
+typedef struct {
+    ora_f3 v0; uint32_t primitive_id_0;
+    ora_f3 v1; uint32_t primitive_id_1;
+    ora_f3 v2; uint16_t rot_x, rot_y;
+    ora_f3 v3; float pad3;
+} ora_triangle_pair;
+
+/* Common.cuh:44-53  (64 B) */
+typedef struct {
+    ora_f3 position; float pitch;
+    ora_f3 w;        float yaw;
+    ora_f3 u;        float scale;
+    ora_f3 v;        float max_depth;
+} ora_camera;
+
+/* Common.cuh:55-59  (72 B: float2 is 8-byte aligned in CUDA) */
+typedef struct {
+    ora_f3 normal[3]; uint32_t pad0;
+    float uv[3][2];
+    int32_t material_id; uint32_t pad1;
+} ora_attributes;
+
+/* POD mirror of the fields of Material the device reads (Common.cuh:93-129) */
+typedef struct {
+    ora_f3 ambient, diffuse, specular;
+    float specular_exp;
+    int32_t texture, bump, disp;
+} ora_material;
+
+enum { ORA_TYPE_NONE = 0, ORA_TYPE_BOX = 1, ORA_TYPE_TRI = 2 };          /* Common.cuh:35-41 */
+enum { ORA_DEPTH = 0, ORA_BOXTESTS = 1, ORA_TRITESTS = 2, ORA_MATERIALID = 3, ORA_DIFFUSE = 5 }; /* Arguments.h:15-26 */
+
+void ora_set_threads(int n);
+int  ora_get_threads(void);
+
+/* DeviceUtils.cuh:3-13 */
+int32_t ora_float_to_ordered_int(float f);
+float   ora_ordered_int_to_float(int32_t i);
+
+/* Multiblock.cu:104-114 + BuildWrapper.cu:288-289 (empty box).  out[6] is ordered-int encoded. */
+void ora_scene_aabb(const ora_triangle* tris, uint32_t n, int32_t out[6]);
+
+/* BottomUpBuilder.cu:12-32,98-115 */
+void ora_morton_codes(const ora_triangle* tris, uint32_t n, const int32_t aabb_ordered[6],
+                      uint32_t* codes, uint32_t* values);
+
+/* RadixSort.cu:171-225 contract: stable ascending LSD sort of (key,value), 4 x 8-bit passes.
+ * tmp_keys/tmp_vals: n entries each. */
+void ora_radix_sort(uint32_t* keys, uint32_t* vals, uint32_t* tmp_keys, uint32_t* tmp_vals, uint32_t n);
+
+/* BottomUpBuilder.cu:34-96,167-215 */
+void ora_generate_hierarchy(ora_node* nodes, uint32_t* leaf_indices, const uint32_t* sorted_codes, uint32_t L);
+
+/* BottomUpBuilder.cu:287-312 with Q1/Q2 resolved (ids defined, no OOB read) */
+void ora_generate_triangles(const uint32_t* sorted_indices, const ora_triangle* tris,
+                            ora_triangle_pair* out, uint32_t L);
+
+/* BottomUpBuilder.cu:217-285 */
+void ora_generate_aabbs(ora_node* nodes, const uint32_t* leaf_indices, const uint32_t* sorted_indices,
+                        uint32_t* locks, const ora_triangle_pair* leaves, uint32_t L);
+
+/* BuildWrapper.cu:253-348 (RunBottomUpBuild, pairs off, not hybrid).  nodes: 2*max(n,1) slots (zeroed
+ * here first), leaves: n.  Optional outputs (may be NULL): codes_sorted[n], indices_sorted[n], aabb[6]. */
+void ora_build(const ora_triangle* tris, uint32_t n, ora_node* nodes, ora_triangle_pair* leaves,
+               uint32_t* codes_sorted, uint32_t* indices_sorted, int32_t* aabb_ordered);
+
+/* Utilities.cpp:8-44 : out[3] = {numNodes, numLeafNodes, numTreeNodes} */
+void ora_count_nodes(const ora_node* nodes, uint32_t root, uint32_t count, int32_t out[3]);
+/* Utilities.cpp:46-83 : returns the number of failing Box slots (reference prints one line each) */
+int  ora_verify_hierarchy(const ora_node* nodes, uint32_t root, uint32_t count);
+
+/* Tracer.cu:471-595 (TraceRays) over rows [y0,y1) of a w x h frame; rgba8 is the full frame (pitch 4w).
+ * spp==1 is the reference; spp>1 is the SURVEY 8(d) config-5 extension.
+ * counters (may be NULL): [0] += sum box_tests, [1] += sum tri_tests, [2] = max stack depth seen.
+ * returns 0, or -1 for an unsupported render type. */
+int ora_trace(const ora_triangle_pair* leaves, const ora_node* nodes, uint32_t root, uint32_t count,
+              const ora_attributes* attributes, const ora_material* materials, uint32_t num_materials,
+              const ora_camera* camera, const float light[3], int render_type,
+              uint8_t* rgba8, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t spp,
+              uint64_t* counters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,199 @@
+"""GPU parity tests proper: the HIP path (through the C ABI of include/rt_abi.h) against the CPU oracle on the
+same seeded inputs.  Integer / index work is bit-exact; boxes are exact float equality; kDepth / kBoxtests /
+kTriangleTests frames are byte-exact; kDiffuse is within 1 LSB per channel (double pow() on device vs libm)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _scenes(scenes):
+    return {
+        "grid24": scenes.grid_mesh(24, 1),          # 1152 tris, the SURVEY appendix-A count case
+        "grid37": scenes.grid_mesh(37, 5),          # 2738 tris: 3 leaf workgroups, ragged tail
+        "soup65536": scenes.soup(65536, 7),         # 25 % duplicate centroids -> cpl index tie-break
+        "flat20": scenes.flat_mesh(20, 3),          # flat axis -> NaN clamp path
+        "soup5000": scenes.soup(5000, 11, dup_fraction=0.9),  # long runs of equal codes
+    }
+
+
+@pytest.fixture(scope="module")
+def built(scenes, ora):
+    from helpers import gpu_build
+    out = {}
+    for name, tris in _scenes(scenes).items():
+        out[name] = (tris, gpu_build(tris), ora.build_bvh(tris))
+    return out
+
+
+@pytest.mark.parametrize("name", ["grid24", "grid37", "soup65536", "flat20", "soup5000"])
+def test_scene_aabb_and_morton(name, built):
+    tris, g, o = built[name]
+    assert (g["aabb"] == o["aabb"]).all(), "ordered-int scene box"
+    assert (g["codes"] == o["codes"]).all(), "sorted Morton codes"
+    assert (g["indices"] == o["indices"]).all(), "sorted triangle indices (stable order)"
+
+
+@pytest.mark.parametrize("name", ["grid24", "grid37", "soup65536", "flat20", "soup5000"])
+def test_nodes_and_leaves_bit_exact(name, built, ora):
+    from helpers import assert_nodes_equal
+    tris, g, o = built[name]
+    n = g["n"]
+    assert_nodes_equal(g["nodes"], o["nodes"], name)
+    assert g["leaves"].tobytes() == o["leaves"].tobytes(), "TrianglePair[] bytes"
+    # the reference's own structural checks (Utilities.cpp), restated and -- when present -- the compiled original
+    assert ora.count_nodes(g["nodes"], 0, 2) == (2 * n - 2, n, n - 2)
+    assert ora.verify_hierarchy(g["nodes"], 0, 2) == 0
+    if ora.ref_available():
+        assert ora.ref_count_nodes(g["nodes"], 0, 2) == (2 * n - 2, n, n - 2)
+        assert ora.ref_verify_hierarchy(g["nodes"], 0, 2) == ""
+
+
+def test_standalone_stage_entry_points(rt, scenes, ora):
+    """rt_calculate_scene_aabb / rt_generate_morton_codes / rt_radix_sort_u32_pairs called on their own."""
+    import torch
+    tris = scenes.soup(10007, 3)
+    n = tris.shape[0]
+    d_tri = rt.to_device(tris)
+    d_aabb = torch.zeros(6, dtype=torch.int32, device="cuda")
+    rt.CalculateSceneAabb(d_tri, n, d_aabb)
+    exp_aabb = ora.scene_aabb(tris)
+    assert (d_aabb.cpu().numpy() == exp_aabb).all()
+    d_codes = torch.zeros(n, dtype=torch.int32, device="cuda")
+    d_vals = torch.zeros(n, dtype=torch.int32, device="cuda")
+    rt.GenerateMortonCodes(d_codes, d_vals, d_tri, d_aabb, n)
+    ec, ev = ora.morton_codes(tris, exp_aabb)
+    assert (d_codes.cpu().numpy().view(np.uint32) == ec).all()
+    assert (d_vals.cpu().numpy().view(np.uint32) == ev).all()
+    t1, t2 = torch.zeros_like(d_codes), torch.zeros_like(d_vals)
+    rt.RadixSort(d_codes, d_vals, t1, t2, n)
+    sk, sv = ora.radix_sort(ec, ev)
+    assert (d_codes.cpu().numpy().view(np.uint32) == sk).all()
+    assert (d_vals.cpu().numpy().view(np.uint32) == sv).all()
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 4095, 4096, 4097, 100003, 1 << 20])
+@pytest.mark.parametrize("bits", [32, 6])
+def test_radix_sort_stable(rt, ora, n, bits):
+    """Full 32-bit keys and heavy-duplicate keys; result must equal a stable sort (values carry input order)."""
+    import torch
+    rng = np.random.default_rng(n * 31 + bits)
+    keys = rng.integers(0, 2 ** bits, size=n, dtype=np.uint64).astype(np.uint32)
+    vals = np.arange(n, dtype=np.uint32)
+    dk, dv = rt.to_device(keys).view(torch.int32), rt.to_device(vals).view(torch.int32)
+    t1, t2 = torch.zeros_like(dk), torch.zeros_like(dv)
+    rt.RadixSort(dk, dv, t1, t2, n)
+    order = np.argsort(keys, kind="stable")
+    assert (dk.cpu().numpy().view(np.uint32) == keys[order]).all()
+    assert (dv.cpu().numpy().view(np.uint32) == vals[order]).all()
+    sk, sv = ora.radix_sort(keys, vals)
+    assert (sk == keys[order]).all() and (sv == vals[order]).all()
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 5])
+def test_tiny_builds(rt, scenes, ora, n):
+    """n < 2 is special-cased; 2..5 exercise a single tiny workgroup."""
+    from helpers import gpu_build, assert_nodes_equal, gpu_trace
+    tris = scenes.soup(max(n, 1), 2, dup_fraction=0.0, size=0.3)[:n]
+    g, o = gpu_build(tris), ora.build_bvh(tris)
+    assert_nodes_equal(g["nodes"], o["nodes"], f"n={n}")
+    assert g["leaves"].tobytes() == o["leaves"].tobytes()
+    cam = scenes.camera_for_box([0, 0, 0], [1, 1, 1])
+    gi, gc = gpu_trace(g, cam, 64, 48)
+    oi, oc = ora.trace(o["leaves"], o["nodes"], 0, 2, cam, 64, 48)
+    assert (gi == oi).all() and (gc == oc[:2]).all()
+
+
+@pytest.mark.parametrize("name,w,h", [("grid24", 256, 256), ("soup65536", 320, 200), ("flat20", 100, 60), ("grid37", 97, 53)])
+@pytest.mark.parametrize("render_type", [0, 1, 2])
+def test_trace_exact_modes(name, w, h, render_type, built, scenes, ora):
+    """kDepth / kBoxtests / kTriangleTests: byte-exact frames and identical test counters."""
+    from helpers import gpu_trace
+    tris, g, o = built[name]
+    lo, hi = ora.ordered_to_float(o["aabb"][:3]), ora.ordered_to_float(o["aabb"][3:])
+    for cam in (scenes.camera_for_box(lo, hi), scenes.camera_for_box(lo, hi, yaw=-2.1, pitch=0.9, back=0.8)):
+        gi, gc = gpu_trace(g, cam, w, h, render_type)
+        oi, oc = ora.trace(o["leaves"], o["nodes"], 0, 2, cam, w, h, render_type=render_type)
+        assert (gc == oc[:2]).all(), f"counters {gc} vs {oc}"
+        diff = np.nonzero((gi != oi).any(axis=2))
+        assert diff[0].size == 0, f"{diff[0].size} pixels differ, first {diff[0][:4]},{diff[1][:4]}"
+
+
+@pytest.mark.parametrize("name", ["grid24", "soup65536"])
+def test_trace_diffuse_and_material_id(name, built, scenes, ora):
+    from helpers import gpu_trace
+    tris, g, o = built[name]
+    n = g["n"]
+    mats = scenes.default_materials(3)
+    at = scenes.flat_attributes(tris, np.arange(n, dtype=np.int32) % 3)
+    lo, hi = ora.ordered_to_float(o["aabb"][:3]), ora.ordered_to_float(o["aabb"][3:])
+    cam = scenes.camera_for_box(lo, hi)
+    light = tuple(float(x) for x in (hi + (hi - lo) * 0.5))
+    for rtype, tol in ((5, 1), (3, 0)):
+        gi, gc = gpu_trace(g, cam, 200, 150, rtype, attributes=at, materials=mats, light=light)
+        oi, oc = ora.trace(o["leaves"], o["nodes"], 0, 2, cam, 200, 150, render_type=rtype, attributes=at,
+                           materials=mats, light=light)
+        d = np.abs(gi.astype(np.int32) - oi.astype(np.int32))
+        assert d.max() <= tol, f"render {rtype}: max channel diff {d.max()}"
+        assert (d > 0).sum() <= 0.001 * d.size, f"render {rtype}: {(d > 0).sum()} channels differ"
+        assert (gc == oc[:2]).all()
+        assert (oi[..., :3].max() > 0), "frame is not empty"
+
+
+def test_trace_row_bands_and_spp(built, scenes, ora):
+    """rows=(y0,y1) bands tile the frame exactly (multi-GPU sharding unit) and the spp extension matches."""
+    from helpers import gpu_trace
+    tris, g, o = built["grid24"]
+    lo, hi = ora.ordered_to_float(o["aabb"][:3]), ora.ordered_to_float(o["aabb"][3:])
+    cam = scenes.camera_for_box(lo, hi)
+    w, h = 128, 101
+    full, fc = gpu_trace(g, cam, w, h, 0)
+    acc = np.zeros_like(full)
+    tot = np.zeros(2, np.uint64)
+    for y0, y1 in ((0, 13), (13, 50), (50, 51), (51, 101)):
+        part, pc = gpu_trace(g, cam, w, h, 0, rows=(y0, y1))
+        assert (part[:y0] == 0).all() and (part[y1:] == 0).all(), "band wrote outside its rows"
+        acc[y0:y1] = part[y0:y1]
+        tot += pc
+    assert (acc == full).all() and (tot == fc).all()
+    for spp in (4, 16):
+        gi, gc = gpu_trace(g, cam, 64, 64, 0, spp=spp)
+        oi, oc = ora.trace(o["leaves"], o["nodes"], 0, 2, cam, 64, 64, render_type=0, spp=spp)
+        assert (gi == oi).all() and (gc == oc[:2]).all()
+
+
+def test_unsupported_options_fail_loudly(rt, scenes):
+    tris = scenes.grid_mesh(4, 1)
+    inp = rt.BuildInput.allocate(tris)
+    with pytest.raises(rt.RtError):
+        rt.RunBottomUpBuild(inp, rt.Arguments(build_type=rt.kBottomUp, enable_pairs=True))
+    with pytest.raises(rt.RtError):
+        rt.RunBottomUpBuild(inp, rt.Arguments(build_type=rt.kBottomUp, enable_splits=True))
+
+
+def test_full_size_1m_properties(rt, scenes, ora):
+    """BASELINE config 2 at full size (grid G=708, 1,002,528 triangles, 1920x1080): size-independent properties
+    plus a full comparison against the oracle (the oracle builds 1M in about a second)."""
+    from helpers import gpu_build, gpu_trace, assert_nodes_equal
+    G = 708
+    tris = scenes.grid_mesh(G, 1)
+    n = tris.shape[0]
+    assert n == 1002528
+    g = gpu_build(tris)
+    assert (np.diff(g["codes"].astype(np.int64)) >= 0).all(), "codes sorted"
+    assert (np.sort(g["indices"]) == np.arange(n)).all(), "indices are a permutation"
+    eq = g["codes"][1:] == g["codes"][:-1]
+    assert (g["indices"][1:][eq] > g["indices"][:-1][eq]).all(), "stable within equal codes"
+    assert ora.count_nodes(g["nodes"], 0, 2) == (2 * n - 2, n, n - 2)
+    assert ora.verify_hierarchy(g["nodes"], 0, 2) == 0
+    if ora.ref_available():
+        assert ora.ref_verify_hierarchy(g["nodes"], 0, 2) == ""
+        assert ora.ref_count_nodes(g["nodes"], 0, 2) == (2 * n - 2, n, n - 2)
+    o = ora.build_bvh(tris)
+    assert_nodes_equal(g["nodes"], o["nodes"], "1M grid")
+    assert g["leaves"].tobytes() == o["leaves"].tobytes()
+    cam = scenes.camera_b(G)
+    gi, gc = gpu_trace(g, cam, 1920, 1080, 0)
+    oi, oc = ora.trace(o["leaves"], o["nodes"], 0, 2, cam, 1920, 1080, render_type=0)
+    assert (gc == oc[:2]).all(), f"{gc} vs {oc}"
+    assert (gi == oi).all()
