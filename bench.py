@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s at 1920x1080 primary rays (+ BVH build ms) on the 1M-triangle procedural mesh.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one frame of the hot path over synthetic input already resident in HBM: every rank traces its row band
+of the 1920x1080 frame against its own replica of the LBVH (the build is deterministic, so replicas are identical)
+and, for N > 1, the bands are gathered into rank 0's frame buffer with one RCCL gather.  The frame is fixed as N
+grows (strong scaling, BASELINE config 3).  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1]): grid_mesh(G=708, seed=1) = 1,002,528 triangles, camera A
+("top-down", 100 % coverage), kDepth, 1 spp.  Camera B, the build time and the CPU baseline are reported as extra
+fields of the same line.
+"""
+import argparse
+import importlib
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--grid", type=int, default=708, help="G of grid_mesh (708 -> 1,002,528 triangles)")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=1)
+    ap.add_argument("--camera", choices=["a", "b"], default="a")
+    ap.add_argument("--render-type", type=int, default=0)
+    ap.add_argument("--build-reps", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip camera B / build timing")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    rt = importlib.import_module("gpu-raytracing_amd")
+    scenes = importlib.import_module("gpu-raytracing_amd.scenes")
+    rt.lib()  # fail loudly if the HIP library is missing
+
+    G, W, H = args.grid, args.width, args.height
+    tris = scenes.grid_mesh(G, 1)
+    n = tris.shape[0]
+    inp = rt.BuildInput.allocate(tris)
+
+    def ev():
+        return torch.cuda.Event(enable_timing=True)
+
+    # ---- build (replicated on every rank); timed with events on the launch stream, scratch preallocated
+    rt.RunBottomUpBuild(inp)
+    torch.cuda.synchronize()
+    build_ms = None
+    if not args.no_extras:
+        times = []
+        for _ in range(args.build_reps):
+            e0, e1 = ev(), ev()
+            e0.record()
+            rt.RunBottomUpBuild(inp)
+            e1.record()
+            e1.synchronize()
+            times.append(e0.elapsed_time(e1))
+        build_ms = statistics.median(times)
+
+    cams = {"a": scenes.camera_a(G), "b": scenes.camera_b(G)}
+    cam_dev = {k: rt.to_device(v) for k, v in cams.items()}
+    frame = torch.zeros(H * W * 4, dtype=torch.uint8, device="cuda")
+    counters = torch.zeros(2, dtype=torch.int64, device="cuda")
+
+    # row bands: rank r renders rows [r*H/N, (r+1)*H/N)
+    bounds = [(r * H) // world for r in range(world + 1)]
+    y0, y1 = bounds[rank], bounds[rank + 1]
+    band = frame[y0 * W * 4:y1 * W * 4]
+    gather_list = None
+    if world > 1 and rank == 0:
+        gather_list = [frame[bounds[r] * W * 4:bounds[r + 1] * W * 4] for r in range(world)]
+    equal_bands = len({bounds[r + 1] - bounds[r] for r in range(world)}) == 1
+
+    def step(cam_key, with_counters=False, events=None):
+        if events is not None:
+            events[0].record()
+        rt.Trace(inp.triangles_out, inp.nodes_out, frame, (W, H), cam_dev[cam_key], 0, 2,
+                 render_type=args.render_type, counters=counters if with_counters else None,
+                 rows=(y0, y1), spp=args.spp)
+        if events is not None:
+            events[1].record()
+        if world > 1:
+            if equal_bands:
+                dist.gather(band, gather_list, dst=0)
+            else:  # ragged bands: point-to-point into place
+                if rank == 0:
+                    reqs = [dist.irecv(gather_list[r], src=r) for r in range(1, world)]
+                    for q in reqs:
+                        q.wait()
+                else:
+                    dist.send(band, dst=0)
+
+    def timed(cam_key, steps, warmup):
+        for _ in range(warmup):
+            step(cam_key)
+        evs = [(ev(), ev()) for _ in range(steps)]
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(cam_key, events=evs[i])
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        kern_ms = statistics.mean(a.elapsed_time(b) for a, b in evs)
+        return dt, kern_ms
+
+    def test_counts(cam_key):
+        counters.zero_()
+        step(cam_key, with_counters=True)
+        torch.cuda.synchronize()
+        c = counters.clone()
+        if world > 1:
+            dist.all_reduce(c)
+        return int(c[0].item()), int(c[1].item())
+
+    cam = args.camera
+    box, tri = test_counts(cam)                      # whole-frame sums (all ranks)
+    dt, kern_ms = timed(cam, args.steps, args.warmup)
+    rays = W * H * args.spp
+    value = rays * args.steps / dt / 1e6
+
+    # local (this rank's band) algorithmic bytes for the roofline of the trace kernel:
+    counters.zero_()
+    rt.Trace(inp.triangles_out, inp.nodes_out, frame, (W, H), cam_dev[cam], 0, 2, render_type=args.render_type,
+             counters=counters, rows=(y0, y1), spp=args.spp)
+    torch.cuda.synchronize()
+    lbox, ltri = int(counters[0].item()), int(counters[1].item())
+    alg_bytes = 32 * lbox + 64 * ltri + 4 * W * (y1 - y0)
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+
+    extras = {}
+    if not args.no_extras:
+        other = "b" if cam == "a" else "a"
+        obox, otri = test_counts(other)
+        odt, okern = timed(other, max(args.steps // 2, 5), 2)
+        extras = {
+            "build_ms": round(build_ms, 4),
+            "build_gbps_algorithmic": round(512.0 * n / (build_ms * 1e-3) / 1e9, 1),  # 512 B/triangle, SURVEY 8(d)
+            f"camera_{other}_mrays": round(rays * max(args.steps // 2, 5) / odt / 1e6, 2),
+            f"camera_{other}_box_tests_per_ray": round(obox / rays, 2),
+        }
+
+    if rank == 0:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "trace_traffic.json")
+        if os.path.exists(tpath) and world == 1 and cam == "a" and (W, H, G, args.spp) == (1920, 1080, 708, 1):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s at 1920x1080 primary rays + BVH build ms, 1M-tri scene",
+            "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"grid_mesh(G={G}, seed=1) = {n} triangles, {W}x{H}, {args.spp} spp, camera "
+                                   f"{cam.upper()} ({'top-down' if cam == 'a' else 'oblique'}), render_type {args.render_type}; "
+                                   "LBVH replicated per GPU",
+                       "parallelism": f"row-bands x{world}" + (" + RCCL gather to rank 0" if world > 1 else "")},
+            "box_tests_per_ray": round(box / rays, 2), "tri_tests_per_ray": round(tri / rays, 3),
+            "roofline": {"bound": "hbm", "kernel": "trace_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(kern_ms, 4),
+                         "formula": "32*sum(box_tests) + 64*sum(tri_tests) + 4*W*rows"},
+        }
+        out.update(extras)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(tris, cams[cam], W, H, args.spp, args.render_type, G)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(tris, cam, W, H, spp, render_type, G):
+    """The oracle (C port of the reference algorithm, OpenMP) timed on this box's host cores on ONE frame of the
+    same workload.  Reported baseline only."""
+    from oracle import oracle_py as ora
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    ora.set_threads(cores)
+    t0 = time.perf_counter()
+    o = ora.build_bvh(tris)
+    t_build = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ora.trace(o["leaves"], o["nodes"], 0, 2, cam, W, H, render_type=render_type, spp=spp)
+    t_trace = time.perf_counter() - t0
+    return {"value": round(W * H * spp / t_trace / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"1 full {W}x{H} frame ({spp} spp) of the same scene and camera, oracle/liboracle.so "
+                      f"(-O2 -ffp-contract=off, OpenMP over rows); LBVH build of the same {tris.shape[0]} triangles",
+            "build_ms": round(t_build * 1e3, 1), "trace_s": round(t_trace, 3)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,32 +1,44 @@
 // trace_kernel.hip -- primary-ray generation, BVH traversal, intersection, shading, RGBA8 store.
 //
 // Replaces TraceRays / TraceRay / IntersectRayAabb / IntersectRayTriangle(Pair) / AmbientShader
-// (Tracer.cu:187-200, 256-374, 376-469, 471-595).  Semantics (and therefore the per-ray box/triangle
-// test counts, which are OUTPUTS of the kBoxtests / kTriangleTests modes) follow the reference
-// exactly: children visited in slot order, leaf hits intersected immediately, nearest Box child
-// continued first (ties: larger child index), the others pushed in encounter order, popped entries
-// are not re-culled.  Machine mapping for wave64:
-//   * one wave = one 8x8 pixel tile (Morton order inside the tile) so the 64 rays of a wave walk
-//     the same upper tree and their 64-byte sibling-pair loads coalesce;
+// (Tracer.cu:187-200, 256-374, 376-469, 471-595).  Per-ray semantics -- and therefore the per-ray box /
+// triangle test counts, which are OUTPUTS of the kBoxtests / kTriangleTests modes -- follow the
+// reference exactly: children visited in slot order, a leaf hit is intersected before the next slot's
+// box is compared against tmax, the nearest Box child is continued first (ties: larger child index),
+// the others are pushed in encounter order, popped entries are not re-culled.
+//
+// Machine mapping for wave64 (what differs from the reference's one-thread-one-ray loop):
+//   * one wave = one 8x8 pixel tile (Morton order inside the tile): the 64 rays walk the same upper
+//     tree, their 64-byte sibling-pair loads hit the same lines (L1 hit rate 97 % on the bench scene);
 //   * a sibling pair (2 x 32-byte slots, 64-byte aligned) is fetched with four 16-byte loads issued
-//     together, before either box is tested;
-//   * the traversal stack is a lane-interleaved LDS column (conflict-free: bank = lane % 32 for both
-//     32-lane halves), entries are one packed dword child:29|count:3; entries beyond the LDS depth
-//     spill to private memory (never on the bench scenes);
+//     together; front/back of BOTH boxes are computed at once (they do not depend on tmax), the
+//     tmax/tmin comparisons are then applied in slot order;
+//   * WAVE-LEVEL TWO-PHASE SCHEDULE: a leaf hit is rare per ray (about 1 in 70 steps) but almost
+//     certain per 64-lane step, and the triangle test is the long divergent path.  A lane that needs a
+//     leaf test parks (phase LEAF0 / LEAF1, keeping the second slot's front/back in registers) and the
+//     wave keeps stepping boxes for the others; when parked lanes outnumber stepping lanes
+//     (one __builtin_amdgcn_ballot_w64 pair per step) the wave runs ONE leaf phase for all of them.
+//     Only the interleaving ACROSS lanes changes; each ray's own sequence of tests is untouched;
+//   * the traversal stack is a lane-interleaved LDS column addressed through an address_space(3)
+//     pointer (ds_read/ds_write; conflict-free: bank = lane % 32 in both 32-lane halves); an entry is
+//     one packed dword child:29|count:3; entries beyond the LDS depth spill to private memory;
 //   * the reference's push-then-pop of the nearest child is kept in a register instead;
 //   * 1/direction is computed once per ray (bit-identical to recomputing it per box: IEEE division);
-//   * test counters are wave-reduced and added with ONE 64-bit atomic per wave (reference: one per ray);
+//   * test counters are wave-reduced and added with ONE 64-bit atomic pair per wave (reference: one
+//     atomic per ray, Tracer.cu:503);
 //   * workgroups are dealt to XCDs round-robin by the hardware, so the tile order is remapped to give
-//     each XCD a contiguous band of the image (its L2 then holds one region of the tree).
+//     each XCD a contiguous band of the image (its L2 then serves one region of the tree).
 // Compiled with -ffp-contract=off: results are bit-identical to the C oracle.
 #include "rt_device.hpp"
 #include "rt_launch.hpp"
 
 namespace rt {
 
-constexpr int kStackLds = 24;    // LDS-resident stack entries per lane
+constexpr int kStackLds = 16;    // LDS-resident stack entries per lane (bench scenes peak at 10)
 constexpr int kStackMax = 64;    // reference stack size (Tracer.cu:314)
 constexpr int kTraceWaves = 4;
+
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
 struct TraceParams {
     const rt_node* nodes;
@@ -38,7 +50,6 @@ struct TraceParams {
     uint32_t root, count, num_materials;
     uint8_t* rgba8;
     uint32_t w, h, y0, y1, spp;
-    int render_type;
     unsigned long long* counters;
     uint32_t tiles_x, num_tiles;
 };
@@ -79,10 +90,30 @@ __device__ __forceinline__ bool intersect_tri(float v0x, float v0y, float v0z, f
     return true;
 }
 
-struct Stack {
-    uint32_t* lds;  // this lane's column: entry k at lds[k * 64]
-    uint32_t spill[kStackMax - kStackLds];
+// per-lane traversal state
+enum : uint32_t { PH_STEP = 0, PH_LEAF0 = 1, PH_LEAF1 = 2, PH_DONE = 3 };
+
+// The private spill array is NOT a member: a dynamically indexed member would pin the whole struct in scratch.
+typedef uint32_t SpillArray[kStackMax - kStackLds];
+
+struct Trav {
+    lds_u32* lds;  // this lane's stack column: entry k at lds[k * 64]
+    uint32_t* spill;
     int sp;
+    uint32_t cur;       // node being visited: first slot : 29 | slot count : 3
+    uint32_t slot_i;    // first slot of the pair being processed (0 unless count > 2)
+    uint32_t near_e;    // nearest Box child so far (packed like cur)
+    float near_d;
+    bool have_near;
+    uint32_t phase;
+    uint32_t leaf;      // pending leaf index
+    // second slot of the current pair, kept while parked in PH_LEAF0
+    float f1, k1;       // front / back
+    uint32_t e1;        // child : 29 | count : 3
+    uint32_t t1;        // type, 0 = none / absent
+    bool tri_hit;
+    uint32_t box_tests, tri_tests;
+
     __device__ __forceinline__ void push(uint32_t e)
     {
         if (sp < kStackLds) lds[sp * 64] = e;
@@ -94,78 +125,126 @@ struct Stack {
         --sp;
         return sp < kStackLds ? lds[sp * 64] : spill[sp - kStackLds];
     }
-};
-
-// Tracer.cu:308-374
-__device__ __forceinline__ bool trace_ray(const TraceParams& p, Ray& r, Hit& h, uint32_t& box_tests,
-                                          uint32_t& tri_tests, Stack& st)
-{
-    bool tri_hit = false;
-    st.sp = 0;
-    uint32_t cur = (p.root & kIndexMask) | (p.count << 29);
-    while (true) {
-        const uint32_t index = cur & kIndexMask, cnt = cur >> 29;
-        bool have_near = false;
-        uint32_t near_e = 0;
-        float near_d = 0.0f;
-        const uint4* np = reinterpret_cast<const uint4*>(p.nodes + index);
-        for (uint32_t i = 0; i < cnt; i += 2) {
-            uint4 q[4];
-            q[0] = np[i * 2 + 0];
-            q[1] = np[i * 2 + 1];
-            const bool two = i + 1 < cnt;
-            if (two) { q[2] = np[i * 2 + 2]; q[3] = np[i * 2 + 3]; }
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                if (k == 1 && !two) break;
-                const uint4 a = q[k * 2], b = q[k * 2 + 1];
-                const uint32_t type = b.w >> 29, child = b.w & kIndexMask, ncount = a.w >> 29;
-                if (type == RT_CHILD_NONE) continue;
-                // IntersectRayAabb (Tracer.cu:187-200)
-                const float t1x = (__uint_as_float(a.x) - r.ox) * r.ix, t2x = (__uint_as_float(b.x) - r.ox) * r.ix;
-                const float t1y = (__uint_as_float(a.y) - r.oy) * r.iy, t2y = (__uint_as_float(b.y) - r.oy) * r.iy;
-                const float t1z = (__uint_as_float(a.z) - r.oz) * r.iz, t2z = (__uint_as_float(b.z) - r.oz) * r.iz;
-                const float front = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
-                const float back = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
-                const bool hit = back >= front && front <= r.tmax && back >= r.tmin;
-                box_tests++;
-                if (!hit) continue;
-                const uint32_t e = child | (ncount << 29);
-                if (type == RT_CHILD_TRI) {
-                    tri_tests++;
-                    const uint4* tp = reinterpret_cast<const uint4*>(p.leaves + child);
-                    const uint4 l0 = tp[0], l1 = tp[1], l2 = tp[2], l3 = tp[3];
-                    // IntersectRayTrianglePair (Tracer.cu:293-306): A = (v0,v1,v2), B = (v2,v1,v3).  B is
-                    // requested whenever count > 0; for a single triangle v3 == v2 bit for bit, edge2 of B
-                    // is exactly 0, a == 0 and the reference rejects it -- skipped here with the same result.
-                    bool hit_tri = intersect_tri(__uint_as_float(l0.x), __uint_as_float(l0.y), __uint_as_float(l0.z),
-                                                 __uint_as_float(l1.x), __uint_as_float(l1.y), __uint_as_float(l1.z),
-                                                 __uint_as_float(l2.x), __uint_as_float(l2.y), __uint_as_float(l2.z),
-                                                 r, h, child << 1, l0.w);
-                    if (ncount > 0 && (l3.x != l2.x || l3.y != l2.y || l3.z != l2.z))
-                        hit_tri |= intersect_tri(__uint_as_float(l2.x), __uint_as_float(l2.y), __uint_as_float(l2.z),
-                                                 __uint_as_float(l1.x), __uint_as_float(l1.y), __uint_as_float(l1.z),
-                                                 __uint_as_float(l3.x), __uint_as_float(l3.y), __uint_as_float(l3.z),
-                                                 r, h, (child << 1) + 1, l1.w);
-                    tri_hit |= hit_tri;
-                } else if (!have_near) {
-                    near_e = e;
-                    near_d = front;
-                    have_near = true;
-                } else if (front < near_d || (front == near_d && child > (near_e & kIndexMask))) {
-                    st.push(near_e);
-                    near_e = e;
-                    near_d = front;
-                } else {
-                    st.push(e);
-                }
+    // a Box child that was hit (Tracer.cu:338-363)
+    __device__ __forceinline__ void inner_hit(uint32_t e, float front)
+    {
+        if (!have_near) {
+            near_e = e; near_d = front; have_near = true;
+        } else if (front < near_d || (front == near_d && (e & kIndexMask) > (near_e & kIndexMask))) {
+            push(near_e);
+            near_e = e; near_d = front;
+        } else {
+            push(e);
+        }
+    }
+    // the current pair is finished: next pair of the same node, the nearest child, a popped entry, or done
+    __device__ __forceinline__ void advance()
+    {
+        if (slot_i + 2 < (cur >> 29)) { slot_i += 2; return; }
+        slot_i = 0;
+        if (have_near) { cur = near_e; have_near = false; }  // the reference pushes it last and pops it first
+        else if (sp == 0) phase = PH_DONE;
+        else cur = pop();
+    }
+    // second slot of the pair, evaluated with the CURRENT tmax (after any leaf hit of the first slot)
+    __device__ __forceinline__ void second_slot(const Ray& r)
+    {
+        if (t1 != RT_CHILD_NONE) {
+            const bool hit = k1 >= f1 && f1 <= r.tmax && k1 >= r.tmin;
+            box_tests++;
+            if (hit) {
+                if (t1 == RT_CHILD_TRI) { leaf = e1 & kIndexMask; phase = PH_LEAF1; leaf_pair = (e1 >> 29) > 0; }
+                else inner_hit(e1, f1);
             }
         }
-        if (have_near) cur = near_e;          // the reference pushes it last and pops it first
-        else if (st.sp == 0) break;
-        else cur = st.pop();
     }
-    return tri_hit;
+    bool leaf_pair;     // node.count > 0 of the pending leaf slot (second triangle requested)
+};
+
+// IntersectRayAabb without the tmax/tmin comparisons (Tracer.cu:187-197): front/back of one slot
+__device__ __forceinline__ void slab(const uint4& a, const uint4& b, const Ray& r, float& front, float& back)
+{
+    const float t1x = (__uint_as_float(a.x) - r.ox) * r.ix, t2x = (__uint_as_float(b.x) - r.ox) * r.ix;
+    const float t1y = (__uint_as_float(a.y) - r.oy) * r.iy, t2y = (__uint_as_float(b.y) - r.oy) * r.iy;
+    const float t1z = (__uint_as_float(a.z) - r.oz) * r.iz, t2z = (__uint_as_float(b.z) - r.oz) * r.iz;
+    front = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
+    back = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
+}
+
+// Tracer.cu:308-374, restructured as described in the file header.  Returns tri_hit.
+__device__ __forceinline__ bool trace_ray(const TraceParams& p, Ray& r, Hit& h, Trav& t, bool active)
+{
+    t.sp = 0;
+    t.cur = (p.root & kIndexMask) | (p.count << 29);
+    t.slot_i = 0;
+    t.have_near = false;
+    t.near_e = 0;
+    t.near_d = 0.0f;
+    t.phase = (active && p.count > 0) ? PH_STEP : PH_DONE;
+    t.tri_hit = false;
+    t.box_tests = 0;
+    t.tri_tests = 0;
+    t.t1 = 0;
+
+    while (true) {
+        const uint64_t stepping = __builtin_amdgcn_ballot_w64(t.phase == PH_STEP);
+        const uint64_t parked = __builtin_amdgcn_ballot_w64(t.phase == PH_LEAF0 || t.phase == PH_LEAF1);
+        if ((stepping | parked) == 0) break;
+        if (__popcll(stepping) >= __popcll(parked) && stepping) {
+            // ------------------------------------------------ box phase
+            if (t.phase == PH_STEP) {
+                const uint32_t cnt = t.cur >> 29;
+                const uint4* np = reinterpret_cast<const uint4*>(p.nodes + (t.cur & kIndexMask) + t.slot_i);
+                const bool two = t.slot_i + 1 < cnt;
+                const uint4 a0 = np[0], b0 = np[1];
+                uint4 a1 = a0, b1 = b0;
+                if (two) { a1 = np[2]; b1 = np[3]; }
+                float f0, k0;
+                slab(a0, b0, r, f0, k0);
+                slab(a1, b1, r, t.f1, t.k1);
+                t.e1 = (b1.w & kIndexMask) | ((a1.w >> 29) << 29);
+                t.t1 = two ? (b1.w >> 29) : (uint32_t)RT_CHILD_NONE;
+                const uint32_t type0 = b0.w >> 29;
+                if (type0 != RT_CHILD_NONE) {
+                    const bool hit = k0 >= f0 && f0 <= r.tmax && k0 >= r.tmin;
+                    t.box_tests++;
+                    if (hit) {
+                        const uint32_t e0 = (b0.w & kIndexMask) | ((a0.w >> 29) << 29);
+                        if (type0 == RT_CHILD_TRI) { t.leaf = e0 & kIndexMask; t.phase = PH_LEAF0; t.leaf_pair = (e0 >> 29) > 0; }
+                        else t.inner_hit(e0, f0);
+                    }
+                }
+                if (t.phase == PH_STEP) {
+                    t.second_slot(r);
+                    if (t.phase == PH_STEP) t.advance();
+                }
+            }
+        } else {
+            // ------------------------------------------------ leaf phase (Tracer.cu:333-337, 293-306)
+            if (t.phase == PH_LEAF0 || t.phase == PH_LEAF1) {
+                t.tri_tests++;
+                const uint4* tp = reinterpret_cast<const uint4*>(p.leaves + t.leaf);
+                const uint4 l0 = tp[0], l1 = tp[1], l2 = tp[2], l3 = tp[3];
+                bool hit_tri = intersect_tri(__uint_as_float(l0.x), __uint_as_float(l0.y), __uint_as_float(l0.z),
+                                             __uint_as_float(l1.x), __uint_as_float(l1.y), __uint_as_float(l1.z),
+                                             __uint_as_float(l2.x), __uint_as_float(l2.y), __uint_as_float(l2.z),
+                                             r, h, t.leaf << 1, l0.w);
+                // triangle B = (v2, v1, v3) is requested whenever count > 0; for a single triangle v3 == v2
+                // bit for bit, B's edge2 is exactly 0, a == 0 and the reference rejects it: skipped, same result.
+                if (t.leaf_pair && (l3.x != l2.x || l3.y != l2.y || l3.z != l2.z))
+                    hit_tri |= intersect_tri(__uint_as_float(l2.x), __uint_as_float(l2.y), __uint_as_float(l2.z),
+                                             __uint_as_float(l1.x), __uint_as_float(l1.y), __uint_as_float(l1.z),
+                                             __uint_as_float(l3.x), __uint_as_float(l3.y), __uint_as_float(l3.z),
+                                             r, h, (t.leaf << 1) + 1, l1.w);
+                t.tri_hit |= hit_tri;
+                const bool was_first = t.phase == PH_LEAF0;
+                t.phase = PH_STEP;
+                if (was_first) t.second_slot(r);
+                if (t.phase == PH_STEP) t.advance();
+            }
+        }
+    }
+    return t.tri_hit;
 }
 
 __device__ __forceinline__ float clampf(float f, float a, float b) { return fmaxf(a, fminf(f, b)); }
@@ -189,10 +268,12 @@ __device__ __forceinline__ void hsv_to_rgb255(float h, float s, float v, float& 
     R = (r + m) * 255; G = (g + m) * 255; B = (b + m) * 255;
 }
 
-// one sample of one pixel -> float colour 0..255 per channel (TraceRays body, Tracer.cu:482-593)
+// one sample of one pixel -> float colour 0..255 per channel (TraceRays body, Tracer.cu:482-593).
+// Every lane of the wave calls this (inactive lanes trace nothing) because trace_ray votes with ballots.
+template <int RENDER>
 __device__ __forceinline__ void shade_sample(const TraceParams& p, const rt_camera& cam, uint32_t x, uint32_t y,
-                                             float ox, float oy, Stack& st, uint32_t& box_acc, uint32_t& tri_acc,
-                                             float& R, float& G, float& B)
+                                             float ox, float oy, Trav& t, bool active, uint32_t& box_acc,
+                                             uint32_t& tri_acc, float& R, float& G, float& B)
 {
     const float ndcx = 2 * (((float)x + ox) / (float)p.w) - 1;
     const float ndcy = 2 * (((float)y + oy) / (float)p.h) - 1;
@@ -208,27 +289,26 @@ __device__ __forceinline__ void shade_sample(const TraceParams& p, const rt_came
     r.tmin = 0.00001f;
     r.tmax = max_depth;
     Hit h = {0u, 0u, 0.f, 0.f};
-    uint32_t box_tests = 0, tri_tests = 0;
-    const bool hit = trace_ray(p, r, h, box_tests, tri_tests, st);
-    box_acc += box_tests;
-    tri_acc += tri_tests;
+    const bool hit = trace_ray(p, r, h, t, active);
+    box_acc += t.box_tests;
+    tri_acc += t.tri_tests;
     const float depth = hit ? r.tmax : 0.0f;
+    R = G = B = 0;
+    if (!active) return;
 
-    if (p.render_type == RT_RENDER_DEPTH) {
+    if (RENDER == RT_RENDER_DEPTH) {
         R = G = B = fminf(1.0f, depth / max_depth) * 255;
         return;
     }
-    if (p.render_type == RT_RENDER_BOXTESTS) {
-        R = 0;
-        G = B = fminf(box_tests / 180.0f, 1.0f) * 255;
+    if (RENDER == RT_RENDER_BOXTESTS) {
+        G = B = fminf(t.box_tests / 180.0f, 1.0f) * 255;
         return;
     }
-    if (p.render_type == RT_RENDER_TRIANGLE_TESTS) {
-        const float g = fminf(tri_tests / 32.0f, 1.0f);
+    if (RENDER == RT_RENDER_TRIANGLE_TESTS) {
+        const float g = fminf(t.tri_tests / 32.0f, 1.0f);
         R = g * 100; G = g * 255; B = g * 100;
         return;
     }
-    R = G = B = 0;
     if (!hit) return;
     // RotateAttributes (Tracer.cu:57-82)
     const rt_triangle_pair* pair = p.leaves + (h.tri_id >> 1);
@@ -238,7 +318,7 @@ __device__ __forceinline__ void shade_sample(const TraceParams& p, const rt_came
     const int i1 = rot == 1 ? 0 : (rot == 2 ? 2 : 1);
     const int i2 = rot == 1 ? 1 : (rot == 2 ? 0 : 2);
     const int material_id = at->material_id;
-    if (p.render_type == RT_RENDER_MATERIAL_ID) {
+    if (RENDER == RT_RENDER_MATERIAL_ID) {
         hsv_to_rgb255((float)material_id / p.num_materials, 1.0f, 1.0f, R, G, B);
         return;
     }
@@ -270,6 +350,7 @@ __device__ __forceinline__ void shade_sample(const TraceParams& p, const rt_came
     B = clampf(cb, 0.0f, 1.0f) * 255;
 }
 
+template <int RENDER>
 __global__ __launch_bounds__(kTraceWaves * 64) void trace_kernel(TraceParams p)
 {
     __shared__ uint32_t stack_lds[kTraceWaves][kStackLds][64];
@@ -288,23 +369,25 @@ __global__ __launch_bounds__(kTraceWaves * 64) void trace_kernel(TraceParams p)
     const uint32_t x = tx * 8 + lx, y = p.y0 + ty * 8 + ly;
     const bool active = tile < p.num_tiles && x < p.w && y < p.y1;
 
+    const rt_camera cam = *p.camera;
+    SpillArray spill;
+    Trav t;
+    t.lds = (lds_u32*)&stack_lds[wave][0][lane];
+    t.spill = spill;
     uint32_t box_acc = 0, tri_acc = 0;
-    if (active) {
-        const rt_camera cam = *p.camera;
-        Stack st;
-        st.lds = &stack_lds[wave][0][lane];
-        float R, G, B;
-        if (p.spp <= 1) {
-            shade_sample(p, cam, x, y, 0.5f, 0.5f, st, box_acc, tri_acc, R, G, B);
-        } else {
-            float ar = 0, ag = 0, ab = 0;
-            for (uint32_t s = 0; s < p.spp; s++) {
-                const float ox = ((float)(s % 4) + 0.5f) / 4.0f, oy = ((float)((s / 4) % 4) + 0.5f) / 4.0f;
-                shade_sample(p, cam, x, y, ox, oy, st, box_acc, tri_acc, R, G, B);
-                ar += R; ag += G; ab += B;
-            }
-            R = ar / (float)p.spp; G = ag / (float)p.spp; B = ab / (float)p.spp;
+    float R, G, B;
+    if (p.spp <= 1) {
+        shade_sample<RENDER>(p, cam, x, y, 0.5f, 0.5f, t, active, box_acc, tri_acc, R, G, B);
+    } else {
+        float ar = 0, ag = 0, ab = 0;
+        for (uint32_t s = 0; s < p.spp; s++) {
+            const float ox = ((float)(s % 4) + 0.5f) / 4.0f, oy = ((float)((s / 4) % 4) + 0.5f) / 4.0f;
+            shade_sample<RENDER>(p, cam, x, y, ox, oy, t, active, box_acc, tri_acc, R, G, B);
+            ar += R; ag += G; ab += B;
         }
+        R = ar / (float)p.spp; G = ag / (float)p.spp; B = ab / (float)p.spp;
+    }
+    if (active) {
         const uint32_t px = (uint32_t)(uint8_t)R | ((uint32_t)(uint8_t)G << 8) | ((uint32_t)(uint8_t)B << 16) | 0xFF000000u;
         reinterpret_cast<uint32_t*>(p.rgba8)[(size_t)y * p.w + x] = px;
     }
@@ -332,13 +415,20 @@ hipError_t launch_trace(const TraceLaunch& t, hipStream_t st)
     p.num_materials = t.scene.num_materials;
     p.rgba8 = t.rgba8;
     p.w = t.w; p.h = t.h; p.y0 = t.y0; p.y1 = t.y1; p.spp = t.spp;
-    p.render_type = t.render_type;
     p.counters = reinterpret_cast<unsigned long long*>(t.counters);
     p.tiles_x = (t.w + 7) / 8;
     const uint32_t tiles_y = (t.y1 - t.y0 + 7) / 8;
     p.num_tiles = p.tiles_x * tiles_y;
     const uint32_t blocks = (p.num_tiles + kTraceWaves - 1) / kTraceWaves;
-    trace_kernel<<<blocks, kTraceWaves * 64, 0, st>>>(p);
+    const dim3 grid(blocks), block(kTraceWaves * 64);
+    switch (t.render_type) {
+    case RT_RENDER_DEPTH: trace_kernel<RT_RENDER_DEPTH><<<grid, block, 0, st>>>(p); break;
+    case RT_RENDER_BOXTESTS: trace_kernel<RT_RENDER_BOXTESTS><<<grid, block, 0, st>>>(p); break;
+    case RT_RENDER_TRIANGLE_TESTS: trace_kernel<RT_RENDER_TRIANGLE_TESTS><<<grid, block, 0, st>>>(p); break;
+    case RT_RENDER_MATERIAL_ID: trace_kernel<RT_RENDER_MATERIAL_ID><<<grid, block, 0, st>>>(p); break;
+    case RT_RENDER_DIFFUSE: trace_kernel<RT_RENDER_DIFFUSE><<<grid, block, 0, st>>>(p); break;
+    default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 
