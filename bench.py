@@ -92,7 +92,7 @@ def main():
     cams = {"a": scenes.camera_a(G), "b": scenes.camera_b(G)}
     cam_dev = {k: rt.to_device(v) for k, v in cams.items()}
     frame = torch.zeros(H * W * 4, dtype=torch.uint8, device="cuda")
-    counters = torch.zeros(2, dtype=torch.int64, device="cuda")
+    counters = torch.zeros(4, dtype=torch.int64, device="cuda")
 
     # row bands: rank r renders rows [r*H/N, (r+1)*H/N)
     bounds = [(r * H) // world for r in range(world + 1)]
@@ -150,10 +150,10 @@ def main():
         c = counters.clone()
         if world > 1:
             dist.all_reduce(c)
-        return int(c[0].item()), int(c[1].item())
+        return [int(v) for v in c.tolist()]
 
     cam = args.camera
-    box, tri = test_counts(cam)                      # whole-frame sums (all ranks)
+    box, tri, wsteps_box, wsteps_leaf = test_counts(cam)   # whole-frame sums (all ranks)
     dt, kern_ms = timed(cam, args.steps, args.warmup)
     rays = W * H * args.spp
     value = rays * args.steps / dt / 1e6
@@ -170,7 +170,7 @@ def main():
     extras = {}
     if not args.no_extras:
         other = "b" if cam == "a" else "a"
-        obox, otri = test_counts(other)
+        obox, otri, _, _ = test_counts(other)
         odt, okern = timed(other, max(args.steps // 2, 5), 2)
         extras = {
             "build_ms": round(build_ms, 4),
@@ -197,6 +197,8 @@ def main():
                                    "LBVH replicated per GPU",
                        "parallelism": f"row-bands x{world}" + (" + RCCL gather to rank 0" if world > 1 else "")},
             "box_tests_per_ray": round(box / rays, 2), "tri_tests_per_ray": round(tri / rays, 3),
+            "wave_steps": {"box_phase": wsteps_box, "leaf_phase": wsteps_leaf,
+                           "lane_utilisation_box_phase": round(box / 2 / max(wsteps_box, 1) / 64, 3)},
             "roofline": {"bound": "hbm", "kernel": "trace_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(kern_ms, 4),

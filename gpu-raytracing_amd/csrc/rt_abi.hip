@@ -127,7 +127,7 @@ int rt_trace(const rt_accel* as, const rt_scene* scene, uint64_t* counters, int 
     if (spp == 0) spp = 1;
     if (spp != 1 && spp != 4 && spp != 16) return RT_ERR_INVALID_ARGUMENT;
     switch (render_type) {
-    case RT_RENDER_DEPTH: case RT_RENDER_BOXTESTS: case RT_RENDER_TRIANGLE_TESTS: break;
+    case RT_RENDER_DEPTH: case RT_RENDER_BOXTESTS: case RT_RENDER_TRIANGLE_TESTS: case 100 /* tuning aid: raw box-test count per pixel */: break;
     case RT_RENDER_MATERIAL_ID: case RT_RENDER_DIFFUSE:
         if (!scene->attributes || !scene->materials || scene->num_materials == 0) return RT_ERR_INVALID_ARGUMENT;
         break;

@@ -29,6 +29,9 @@
 //   * workgroups are dealt to XCDs round-robin by the hardware, so the tile order is remapped to give
 //     each XCD a contiguous band of the image (its L2 then serves one region of the tree).
 // Compiled with -ffp-contract=off: results are bit-identical to the C oracle.
+#include <cstdio>
+#include <cstdlib>
+
 #include "rt_device.hpp"
 #include "rt_launch.hpp"
 
@@ -37,6 +40,10 @@ namespace rt {
 constexpr int kStackLds = 16;    // LDS-resident stack entries per lane (bench scenes peak at 10)
 constexpr int kStackMax = 64;    // reference stack size (Tracer.cu:314)
 constexpr int kTraceWaves = 4;
+constexpr int kRenderDebugBoxCount = 100;  // internal tuning aid (not in the ABI enum): pixel = raw u32 box-test count
+// the wave runs a box step while  stepping * park_den >= parked * park_num  (else one leaf phase);
+// defaults below, RT_TRACE_PARK="num,den" overrides them at run time (tuning knob).
+constexpr int kParkNum = 8, kParkDen = 1;
 
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
@@ -52,6 +59,7 @@ struct TraceParams {
     uint32_t w, h, y0, y1, spp;
     unsigned long long* counters;
     uint32_t tiles_x, num_tiles;
+    int park_num, park_den;
 };
 
 struct Ray {
@@ -92,6 +100,7 @@ __device__ __forceinline__ bool intersect_tri(float v0x, float v0y, float v0z, f
 
 // per-lane traversal state
 enum : uint32_t { PH_STEP = 0, PH_LEAF0 = 1, PH_LEAF1 = 2, PH_DONE = 3 };
+constexpr uint32_t kNoNear = 0xFFFFFFFFu;  // "no Box child hit yet" (child 2^29-1, count 7: not a real entry)
 
 // The private spill array is NOT a member: a dynamically indexed member would pin the whole struct in scratch.
 typedef uint32_t SpillArray[kStackMax - kStackLds];
@@ -100,151 +109,149 @@ struct Trav {
     lds_u32* lds;  // this lane's stack column: entry k at lds[k * 64]
     uint32_t* spill;
     int sp;
-    uint32_t cur;       // node being visited: first slot : 29 | slot count : 3
-    uint32_t slot_i;    // first slot of the pair being processed (0 unless count > 2)
-    uint32_t near_e;    // nearest Box child so far (packed like cur)
-    float near_d;
-    bool have_near;
+    uint32_t cur;       // slots still to visit of the current node: first slot : 29 | slot count : 3
+    uint32_t near_e;    // nearest Box child so far (packed like cur) or kNoNear
+    float near_d;       // its front distance (+inf while kNoNear)
     uint32_t phase;
-    uint32_t leaf;      // pending leaf index
+    uint32_t leaf;      // pending leaf: index : 29 | count : 3
     // second slot of the current pair, kept while parked in PH_LEAF0
     float f1, k1;       // front / back
     uint32_t e1;        // child : 29 | count : 3
     uint32_t t1;        // type, 0 = none / absent
-    bool tri_hit;
     uint32_t box_tests, tri_tests;
 
     __device__ __forceinline__ void push(uint32_t e)
     {
         if (sp < kStackLds) lds[sp * 64] = e;
         else if (sp < kStackMax) spill[sp - kStackLds] = e;
-        if (sp < kStackMax) sp++;  // a 65th push is dropped (the reference overruns its array, Tracer.cu:353-369)
+        sp = min(sp + 1, kStackMax);  // a 65th push is dropped (the reference overruns its array, Tracer.cu:353-369)
     }
-    __device__ __forceinline__ uint32_t pop()
+    // A Box child (Tracer.cu:338-363), predicated on `in`: the first hit becomes `near`; a closer one (ties:
+    // larger child index) displaces `near` onto the stack; otherwise it is pushed itself.  Bitwise logic on
+    // purpose (no short-circuit branches); with no near yet near_d = +inf makes every hit "closer".
+    __device__ __forceinline__ void inner_hit(bool in, uint32_t e, float front)
     {
-        --sp;
-        return sp < kStackLds ? lds[sp * 64] : spill[sp - kStackLds];
+        const bool closer = (front < near_d) | ((front == near_d) & ((e & kIndexMask) > (near_e & kIndexMask)));
+        if (in & (near_e != kNoNear)) push(closer ? near_e : e);
+        const bool take = in & closer;
+        near_e = take ? e : near_e;
+        near_d = take ? front : near_d;
     }
-    // a Box child that was hit (Tracer.cu:338-363)
-    __device__ __forceinline__ void inner_hit(uint32_t e, float front)
-    {
-        if (!have_near) {
-            near_e = e; near_d = front; have_near = true;
-        } else if (front < near_d || (front == near_d && (e & kIndexMask) > (near_e & kIndexMask))) {
-            push(near_e);
-            near_e = e; near_d = front;
-        } else {
-            push(e);
-        }
-    }
-    // the current pair is finished: next pair of the same node, the nearest child, a popped entry, or done
+    // the current pair is finished: remaining slots of the same node (count > 2 only, never in an LBVH), else
+    // the nearest child (the reference pushes it last and pops it first), else a popped entry, else done
     __device__ __forceinline__ void advance()
     {
-        if (slot_i + 2 < (cur >> 29)) { slot_i += 2; return; }
-        slot_i = 0;
-        if (have_near) { cur = near_e; have_near = false; }  // the reference pushes it last and pops it first
+        const uint32_t cnt = cur >> 29;
+        if (cnt > 2) { cur = ((cur & kIndexMask) + 2) | ((cnt - 2) << 29); return; }
+        if (near_e != kNoNear) { cur = near_e; near_e = kNoNear; near_d = __builtin_inff(); }
         else if (sp == 0) phase = PH_DONE;
-        else cur = pop();
+        else { --sp; cur = sp < kStackLds ? lds[sp * 64] : spill[sp - kStackLds]; }
     }
     // second slot of the pair, evaluated with the CURRENT tmax (after any leaf hit of the first slot)
-    __device__ __forceinline__ void second_slot(const Ray& r)
+    __device__ __forceinline__ void second_slot(float tmin, float tmax)
     {
-        if (t1 != RT_CHILD_NONE) {
-            const bool hit = k1 >= f1 && f1 <= r.tmax && k1 >= r.tmin;
-            box_tests++;
-            if (hit) {
-                if (t1 == RT_CHILD_TRI) { leaf = e1 & kIndexMask; phase = PH_LEAF1; leaf_pair = (e1 >> 29) > 0; }
-                else inner_hit(e1, f1);
-            }
-        }
+        const bool valid = t1 != RT_CHILD_NONE;
+        const bool hit = valid & (k1 >= f1) & (f1 <= tmax) & (k1 >= tmin);
+        box_tests += valid ? 1u : 0u;
+        const bool is_leaf = hit & (t1 == RT_CHILD_TRI);
+        inner_hit(hit & !is_leaf, e1, f1);
+        if (is_leaf) { leaf = e1; phase = PH_LEAF1; }
     }
-    bool leaf_pair;     // node.count > 0 of the pending leaf slot (second triangle requested)
 };
 
 // IntersectRayAabb without the tmax/tmin comparisons (Tracer.cu:187-197): front/back of one slot
 __device__ __forceinline__ void slab(const uint4& a, const uint4& b, const Ray& r, float& front, float& back)
 {
-    const float t1x = (__uint_as_float(a.x) - r.ox) * r.ix, t2x = (__uint_as_float(b.x) - r.ox) * r.ix;
-    const float t1y = (__uint_as_float(a.y) - r.oy) * r.iy, t2y = (__uint_as_float(b.y) - r.oy) * r.iy;
+    // x and y go through v_pk_add_f32 / v_pk_mul_f32 (two IEEE f32 ops per instruction, same rounding)
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f o2 = {r.ox, r.oy}, i2 = {r.ix, r.iy};
+    const v2f lo = {__uint_as_float(a.x), __uint_as_float(a.y)}, hi = {__uint_as_float(b.x), __uint_as_float(b.y)};
+    const v2f t1 = (lo - o2) * i2, t2 = (hi - o2) * i2;
     const float t1z = (__uint_as_float(a.z) - r.oz) * r.iz, t2z = (__uint_as_float(b.z) - r.oz) * r.iz;
-    front = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
-    back = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
+    front = fmaxf(fmaxf(fminf(t1.x, t2.x), fminf(t1.y, t2.y)), fminf(t1z, t2z));
+    back = fminf(fminf(fmaxf(t1.x, t2.x), fmaxf(t1.y, t2.y)), fmaxf(t1z, t2z));
 }
 
 // Tracer.cu:308-374, restructured as described in the file header.  Returns tri_hit.
-__device__ __forceinline__ bool trace_ray(const TraceParams& p, Ray& r, Hit& h, Trav& t, bool active)
+// steps[0] / steps[1] count the wave's box-phase / leaf-phase iterations (profiling aid).
+__device__ __forceinline__ bool trace_ray(const TraceParams& p, Ray& r, Hit& h, Trav& t, bool active, uint32_t* steps)
 {
     t.sp = 0;
     t.cur = (p.root & kIndexMask) | (p.count << 29);
-    t.slot_i = 0;
-    t.have_near = false;
-    t.near_e = 0;
-    t.near_d = 0.0f;
+    t.near_e = kNoNear;
+    t.near_d = __builtin_inff();
     t.phase = (active && p.count > 0) ? PH_STEP : PH_DONE;
-    t.tri_hit = false;
     t.box_tests = 0;
     t.tri_tests = 0;
     t.t1 = 0;
+    t.e1 = 0;
+    t.f1 = t.k1 = 0.0f;
+    t.leaf = 0;
+    bool tri_hit = false;
+    uint32_t nbox = 0, nleaf = 0;
 
     while (true) {
-        const uint64_t stepping = __builtin_amdgcn_ballot_w64(t.phase == PH_STEP);
-        const uint64_t parked = __builtin_amdgcn_ballot_w64(t.phase == PH_LEAF0 || t.phase == PH_LEAF1);
-        if ((stepping | parked) == 0) break;
-        if (__popcll(stepping) >= __popcll(parked) && stepping) {
-            // ------------------------------------------------ box phase
+        // ---------------------------------------------------- box phase: step while enough lanes want to
+        uint64_t stepping, parked;
+        while (true) {
+            stepping = __builtin_amdgcn_ballot_w64(t.phase == PH_STEP);
+            parked = __builtin_amdgcn_ballot_w64((t.phase - 1u) < 2u);
+            if (stepping == 0 || __popcll(stepping) * p.park_den < __popcll(parked) * p.park_num) break;
+            nbox++;
             if (t.phase == PH_STEP) {
                 const uint32_t cnt = t.cur >> 29;
-                const uint4* np = reinterpret_cast<const uint4*>(p.nodes + (t.cur & kIndexMask) + t.slot_i);
-                const bool two = t.slot_i + 1 < cnt;
-                const uint4 a0 = np[0], b0 = np[1];
-                uint4 a1 = a0, b1 = b0;
-                if (two) { a1 = np[2]; b1 = np[3]; }
+                const uint4* np = reinterpret_cast<const uint4*>(p.nodes + (t.cur & kIndexMask));
+                const bool two = cnt > 1;
+                const int o1 = two ? 2 : 0;  // all four loads issue together; a lone slot is simply read twice
+                const uint4 a0 = np[0], b0 = np[1], a1 = np[o1], b1 = np[o1 + 1];
                 float f0, k0;
                 slab(a0, b0, r, f0, k0);
                 slab(a1, b1, r, t.f1, t.k1);
-                t.e1 = (b1.w & kIndexMask) | ((a1.w >> 29) << 29);
+                t.e1 = (b1.w & kIndexMask) | (a1.w & ~kIndexMask);
                 t.t1 = two ? (b1.w >> 29) : (uint32_t)RT_CHILD_NONE;
                 const uint32_t type0 = b0.w >> 29;
-                if (type0 != RT_CHILD_NONE) {
-                    const bool hit = k0 >= f0 && f0 <= r.tmax && k0 >= r.tmin;
-                    t.box_tests++;
-                    if (hit) {
-                        const uint32_t e0 = (b0.w & kIndexMask) | ((a0.w >> 29) << 29);
-                        if (type0 == RT_CHILD_TRI) { t.leaf = e0 & kIndexMask; t.phase = PH_LEAF0; t.leaf_pair = (e0 >> 29) > 0; }
-                        else t.inner_hit(e0, f0);
-                    }
-                }
-                if (t.phase == PH_STEP) {
-                    t.second_slot(r);
+                const uint32_t e0 = (b0.w & kIndexMask) | (a0.w & ~kIndexMask);
+                const bool valid0 = type0 != RT_CHILD_NONE;
+                const bool hit0 = valid0 & (k0 >= f0) & (f0 <= r.tmax) & (k0 >= r.tmin);
+                t.box_tests += valid0 ? 1u : 0u;
+                const bool leaf0 = hit0 & (type0 == RT_CHILD_TRI);
+                t.inner_hit(hit0 & !leaf0, e0, f0);
+                if (leaf0) { t.leaf = e0; t.phase = PH_LEAF0; }
+                else {
+                    t.second_slot(r.tmin, r.tmax);
                     if (t.phase == PH_STEP) t.advance();
                 }
             }
-        } else {
-            // ------------------------------------------------ leaf phase (Tracer.cu:333-337, 293-306)
-            if (t.phase == PH_LEAF0 || t.phase == PH_LEAF1) {
-                t.tri_tests++;
-                const uint4* tp = reinterpret_cast<const uint4*>(p.leaves + t.leaf);
-                const uint4 l0 = tp[0], l1 = tp[1], l2 = tp[2], l3 = tp[3];
-                bool hit_tri = intersect_tri(__uint_as_float(l0.x), __uint_as_float(l0.y), __uint_as_float(l0.z),
-                                             __uint_as_float(l1.x), __uint_as_float(l1.y), __uint_as_float(l1.z),
-                                             __uint_as_float(l2.x), __uint_as_float(l2.y), __uint_as_float(l2.z),
-                                             r, h, t.leaf << 1, l0.w);
-                // triangle B = (v2, v1, v3) is requested whenever count > 0; for a single triangle v3 == v2
-                // bit for bit, B's edge2 is exactly 0, a == 0 and the reference rejects it: skipped, same result.
-                if (t.leaf_pair && (l3.x != l2.x || l3.y != l2.y || l3.z != l2.z))
-                    hit_tri |= intersect_tri(__uint_as_float(l2.x), __uint_as_float(l2.y), __uint_as_float(l2.z),
-                                             __uint_as_float(l1.x), __uint_as_float(l1.y), __uint_as_float(l1.z),
-                                             __uint_as_float(l3.x), __uint_as_float(l3.y), __uint_as_float(l3.z),
-                                             r, h, (t.leaf << 1) + 1, l1.w);
-                t.tri_hit |= hit_tri;
-                const bool was_first = t.phase == PH_LEAF0;
-                t.phase = PH_STEP;
-                if (was_first) t.second_slot(r);
-                if (t.phase == PH_STEP) t.advance();
-            }
+        }
+        if ((stepping | parked) == 0) break;
+        // ---------------------------------------------------- leaf phase (Tracer.cu:333-337, 293-306)
+        nleaf++;
+        if ((t.phase - 1u) < 2u) {
+            t.tri_tests++;
+            const uint32_t li = t.leaf & kIndexMask;
+            const uint4* tp = reinterpret_cast<const uint4*>(p.leaves + li);
+            const uint4 l0 = tp[0], l1 = tp[1], l2 = tp[2], l3 = tp[3];
+            bool hit_tri = intersect_tri(__uint_as_float(l0.x), __uint_as_float(l0.y), __uint_as_float(l0.z),
+                                         __uint_as_float(l1.x), __uint_as_float(l1.y), __uint_as_float(l1.z),
+                                         __uint_as_float(l2.x), __uint_as_float(l2.y), __uint_as_float(l2.z),
+                                         r, h, li << 1, l0.w);
+            // triangle B = (v2, v1, v3) is requested whenever count > 0; for a single triangle v3 == v2
+            // bit for bit, B's edge2 is exactly 0, a == 0 and the reference rejects it: skipped, same result.
+            if ((t.leaf >> 29) > 0 && (l3.x != l2.x || l3.y != l2.y || l3.z != l2.z))
+                hit_tri |= intersect_tri(__uint_as_float(l2.x), __uint_as_float(l2.y), __uint_as_float(l2.z),
+                                         __uint_as_float(l1.x), __uint_as_float(l1.y), __uint_as_float(l1.z),
+                                         __uint_as_float(l3.x), __uint_as_float(l3.y), __uint_as_float(l3.z),
+                                         r, h, (li << 1) + 1, l1.w);
+            tri_hit |= hit_tri;
+            const bool was_first = t.phase == PH_LEAF0;
+            t.phase = PH_STEP;
+            if (was_first) t.second_slot(r.tmin, r.tmax);
+            if (t.phase == PH_STEP) t.advance();
         }
     }
-    return t.tri_hit;
+    steps[0] += nbox;
+    steps[1] += nleaf;
+    return tri_hit;
 }
 
 __device__ __forceinline__ float clampf(float f, float a, float b) { return fmaxf(a, fminf(f, b)); }
@@ -273,7 +280,7 @@ __device__ __forceinline__ void hsv_to_rgb255(float h, float s, float v, float& 
 template <int RENDER>
 __device__ __forceinline__ void shade_sample(const TraceParams& p, const rt_camera& cam, uint32_t x, uint32_t y,
                                              float ox, float oy, Trav& t, bool active, uint32_t& box_acc,
-                                             uint32_t& tri_acc, float& R, float& G, float& B)
+                                             uint32_t& tri_acc, uint32_t* steps, float& R, float& G, float& B)
 {
     const float ndcx = 2 * (((float)x + ox) / (float)p.w) - 1;
     const float ndcy = 2 * (((float)y + oy) / (float)p.h) - 1;
@@ -289,7 +296,7 @@ __device__ __forceinline__ void shade_sample(const TraceParams& p, const rt_came
     r.tmin = 0.00001f;
     r.tmax = max_depth;
     Hit h = {0u, 0u, 0.f, 0.f};
-    const bool hit = trace_ray(p, r, h, t, active);
+    const bool hit = trace_ray(p, r, h, t, active, steps);
     box_acc += t.box_tests;
     tri_acc += t.tri_tests;
     const float depth = hit ? r.tmax : 0.0f;
@@ -302,6 +309,10 @@ __device__ __forceinline__ void shade_sample(const TraceParams& p, const rt_came
     }
     if (RENDER == RT_RENDER_BOXTESTS) {
         G = B = fminf(t.box_tests / 180.0f, 1.0f) * 255;
+        return;
+    }
+    if (RENDER == kRenderDebugBoxCount) {  // tuning aid: R carries the raw count (bit pattern), see trace_kernel
+        R = __uint_as_float(t.box_tests);
         return;
     }
     if (RENDER == RT_RENDER_TRIANGLE_TESTS) {
@@ -375,20 +386,22 @@ __global__ __launch_bounds__(kTraceWaves * 64) void trace_kernel(TraceParams p)
     t.lds = (lds_u32*)&stack_lds[wave][0][lane];
     t.spill = spill;
     uint32_t box_acc = 0, tri_acc = 0;
+    uint32_t steps[2] = {0u, 0u};
     float R, G, B;
     if (p.spp <= 1) {
-        shade_sample<RENDER>(p, cam, x, y, 0.5f, 0.5f, t, active, box_acc, tri_acc, R, G, B);
+        shade_sample<RENDER>(p, cam, x, y, 0.5f, 0.5f, t, active, box_acc, tri_acc, steps, R, G, B);
     } else {
         float ar = 0, ag = 0, ab = 0;
         for (uint32_t s = 0; s < p.spp; s++) {
             const float ox = ((float)(s % 4) + 0.5f) / 4.0f, oy = ((float)((s / 4) % 4) + 0.5f) / 4.0f;
-            shade_sample<RENDER>(p, cam, x, y, ox, oy, t, active, box_acc, tri_acc, R, G, B);
+            shade_sample<RENDER>(p, cam, x, y, ox, oy, t, active, box_acc, tri_acc, steps, R, G, B);
             ar += R; ag += G; ab += B;
         }
         R = ar / (float)p.spp; G = ag / (float)p.spp; B = ab / (float)p.spp;
     }
     if (active) {
-        const uint32_t px = (uint32_t)(uint8_t)R | ((uint32_t)(uint8_t)G << 8) | ((uint32_t)(uint8_t)B << 16) | 0xFF000000u;
+        uint32_t px = (uint32_t)(uint8_t)R | ((uint32_t)(uint8_t)G << 8) | ((uint32_t)(uint8_t)B << 16) | 0xFF000000u;
+        if (RENDER == kRenderDebugBoxCount) px = __float_as_uint(R);
         reinterpret_cast<uint32_t*>(p.rgba8)[(size_t)y * p.w + x] = px;
     }
     if (p.counters) {
@@ -396,6 +409,8 @@ __global__ __launch_bounds__(kTraceWaves * 64) void trace_kernel(TraceParams p)
         if (lane == 0 && (bsum | tsum)) {
             atomicAdd(&p.counters[0], (unsigned long long)bsum);
             atomicAdd(&p.counters[1], (unsigned long long)tsum);
+            atomicAdd(&p.counters[2], (unsigned long long)steps[0]);  // wave-level box-phase steps (profiling)
+            atomicAdd(&p.counters[3], (unsigned long long)steps[1]);  // wave-level leaf-phase steps
         }
     }
 }
@@ -419,6 +434,16 @@ hipError_t launch_trace(const TraceLaunch& t, hipStream_t st)
     p.tiles_x = (t.w + 7) / 8;
     const uint32_t tiles_y = (t.y1 - t.y0 + 7) / 8;
     p.num_tiles = p.tiles_x * tiles_y;
+    static const int* park = [] {
+        static int v[2] = {kParkNum, kParkDen};
+        if (const char* e = getenv("RT_TRACE_PARK")) {
+            int a = 0, b = 0;
+            if (sscanf(e, "%d,%d", &a, &b) == 2 && a > 0 && b > 0) { v[0] = a; v[1] = b; }
+        }
+        return v;
+    }();
+    p.park_num = park[0];
+    p.park_den = park[1];
     const uint32_t blocks = (p.num_tiles + kTraceWaves - 1) / kTraceWaves;
     const dim3 grid(blocks), block(kTraceWaves * 64);
     switch (t.render_type) {
@@ -427,6 +452,7 @@ hipError_t launch_trace(const TraceLaunch& t, hipStream_t st)
     case RT_RENDER_TRIANGLE_TESTS: trace_kernel<RT_RENDER_TRIANGLE_TESTS><<<grid, block, 0, st>>>(p); break;
     case RT_RENDER_MATERIAL_ID: trace_kernel<RT_RENDER_MATERIAL_ID><<<grid, block, 0, st>>>(p); break;
     case RT_RENDER_DIFFUSE: trace_kernel<RT_RENDER_DIFFUSE><<<grid, block, 0, st>>>(p); break;
+    case kRenderDebugBoxCount: trace_kernel<kRenderDebugBoxCount><<<grid, block, 0, st>>>(p); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -143,8 +143,8 @@ int rt_radix_sort_u32_pairs(uint32_t* keys, uint32_t* values, uint32_t* tmp_keys
 
 /* replaces Trace()/TraceRays (main.cu:125-192, Tracer.cu:471-595) for rows [y0, y1) of a w x h frame.
  * rgba8: full-frame linear RGBA8 buffer, pitch 4*w, row 0 first (= the surface contents, SURVEY A).
- * counters: optional device uint64[2], [0] += sum of box tests, [1] += sum of triangle tests
- * (the reference's num_tests is [0], Tracer.cu:503).  spp = 1 is the reference; spp in {4,16} is the
+ * counters: optional device uint64[4], [0] += sum of box tests, [1] += sum of triangle tests (the reference's
+ * num_tests is [0], Tracer.cu:503); [2] / [3] += wave-level box-phase / leaf-phase steps (profiling aid).  spp = 1 is the reference; spp in {4,16} is the
  * SURVEY 8(d) config-5 extension (4x4 stratified offsets, averaged before the u8 truncation). */
 int rt_trace(const rt_accel* as, const rt_scene* scene, uint64_t* counters, int render_type, uint8_t* rgba8,
              uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t spp, void* stream);

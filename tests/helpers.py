@@ -35,14 +35,14 @@ def gpu_trace(build, camera, w, h, render_type=0, attributes=None, materials=Non
     inp = build["inp"]
     cam_d = rt.to_device(camera)
     rgba = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
-    counters = torch.zeros(2, dtype=torch.int64, device="cuda")
+    counters = torch.zeros(4, dtype=torch.int64, device="cuda")
     at_d = rt.to_device(attributes) if attributes is not None else None
     mt_d = rt.to_device(materials) if materials is not None else None
     rt.Trace(inp.triangles_out, inp.nodes_out, rgba, (w, h), cam_d, root, count, render_type=render_type,
              attributes=at_d, materials=mt_d, num_materials=0 if materials is None else materials.shape[0],
              light=light, counters=counters, rows=rows, spp=spp)
     torch.cuda.synchronize()
-    return rgba.cpu().numpy().reshape(h, w, 4), counters.cpu().numpy().astype(np.uint64)
+    return rgba.cpu().numpy().reshape(h, w, 4), counters.cpu().numpy().astype(np.uint64)[:2]
 
 
 def assert_nodes_equal(got: np.ndarray, exp: np.ndarray, what=""):
