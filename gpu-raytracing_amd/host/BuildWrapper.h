@@ -1,0 +1,23 @@
+// BuildWrapper.h -- the reference's BuildWrapper.cuh:6-20 entry points over the C ABI (include/rt_abi.h).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+#include "Arguments.h"
+#include "Common.h"
+
+struct BuildInput {              // BuildWrapper.cuh:6-12 (all device pointers, owned by the caller)
+    Triangle* triangles_in;
+    TrianglePair* triangles_out;
+    unsigned num_triangles;
+    Node* nodes_out;
+    void* scratch;
+};
+
+size_t BuMemoryRequirements(uint32_t num_triangles);                       // BuildWrapper.cu:132-136
+// Launches the LBVH build on `stream` (default stream when null) and returns without synchronising (the reference
+// synchronises after every kernel through its run() macro).  Error convention of the reference: message + exit.
+void RunBottomUpBuild(BuildInput input, Arguments args, bool hybrid, void* stream = nullptr);  // BuildWrapper.cu:253-362
+// SAH builder: SURVEY 8(f) rank 3, not built; calling it reports "unsupported" and exits like any other error.
+size_t SahMemoryRequirements(uint32_t num_triangles);
+void RunSahBuild(BuildInput input, Arguments args);

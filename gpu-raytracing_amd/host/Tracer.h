@@ -1,0 +1,20 @@
+// Tracer.h -- the reference's Trace() (main.cu:125-192) / TraceRays (Tracer.cuh:21-23) over the C ABI.
+#pragma once
+#include <cstdint>
+
+#include "Arguments.h"
+#include "Common.h"
+
+struct DeviceSceneView {             // the fields of DeviceScene (Common.cuh:342-351) Trace() fills at main.cu:159-167
+    const Attributes* attributes = nullptr;   // device
+    const rt_material* materials = nullptr;   // device
+    uint32_t num_attributes = 0, num_materials = 0;
+    vec3 light{0, 0, 0};
+};
+
+// One frame: rows [y0, y1) of a dims_x x dims_y RGBA8 frame (linear device buffer, row 0 first -- the contents of
+// the reference's GL surface).  num_tests: optional device uint64[4] ([0] = sum of box tests as printed by the
+// reference at main.cu:180-183).  Asynchronous on `stream`.
+void Trace(const TrianglePair* triangles, const Node* nodes, uint8_t* rgba8, int dims_x, int dims_y, const Camera* camera_dev,
+           unsigned root, unsigned count, RenderType render_type, const DeviceSceneView& scene, uint64_t* num_tests,
+           unsigned y0, unsigned y1, unsigned spp = 1, void* stream = nullptr);

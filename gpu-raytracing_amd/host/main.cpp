@@ -1,0 +1,151 @@
+// main.cpp -- headless counterpart of the reference's main.cu: what Display() does at frame 0 (main.cu:215-265)
+// plus one Trace() (main.cu:125-192), with the frame written as a PPM instead of shown in a GL window.
+//
+//   rt_cli <file.obj> [--type bottom-up|hybrid] [--pairs] [--splits] [--render depth|boxtests|tritests|material|diffuse]
+//          [--width W] [--height H] [--spp N] [--yaw Y --pitch P --pos X Y Z] [--out frame.ppm] [--frames K]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "Arguments.h"
+#include "BuildWrapper.h"
+#include "Camera.h"
+#include "FileIO.h"
+#include "MemoryBuffer.h"
+#include "Tracer.h"
+#include "Utilities.h"
+
+static RenderType ParseRender(const std::string& s)
+{
+    if (s == "boxtests") return kBoxtests;
+    if (s == "tritests") return kTriangleTests;
+    if (s == "material") return kMaterialId;
+    if (s == "diffuse") return kDiffuse;
+    return kDepth;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 2) {
+        fprintf(stderr, "usage: %s <file.obj> [--type bottom-up|hybrid] [--render depth|boxtests|tritests|material|diffuse] "
+                        "[--width W] [--height H] [--spp N] [--yaw Y] [--pitch P] [--pos X Y Z] [--out f.ppm] [--frames K]\n", argv[0]);
+        return 2;
+    }
+    Arguments args = ParseCmd(argc, argv);
+    if (args.build_type == kSAH) args.build_type = kBottomUp;  // the SAH builder is not part of this build
+    int width = 1024, height = 768, frames = 1;                 // the reference's window size (main.cu:44-45)
+    unsigned spp = 1;
+    std::string out;
+    bool have_pos = false, have_yaw = false, have_pitch = false;
+    vec3 pos{0, 0, 0};
+    float yaw = 0, pitch = 0;
+    for (int i = 2; i < argc; i++) {
+        const std::string a = argv[i];
+        auto next = [&](int k) { return i + k < argc ? argv[i + k] : "0"; };
+        if (a == "--render") { args.render_type = ParseRender(next(1)); i++; }
+        else if (a == "--width") { width = atoi(next(1)); i++; }
+        else if (a == "--height") { height = atoi(next(1)); i++; }
+        else if (a == "--spp") { spp = (unsigned)atoi(next(1)); i++; }
+        else if (a == "--frames") { frames = atoi(next(1)); i++; }
+        else if (a == "--out") { out = next(1); i++; }
+        else if (a == "--yaw") { yaw = (float)atof(next(1)); have_yaw = true; i++; }
+        else if (a == "--pitch") { pitch = (float)atof(next(1)); have_pitch = true; i++; }
+        else if (a == "--pos") { pos = make_vec3((float)atof(next(1)), (float)atof(next(2)), (float)atof(next(3))); have_pos = true; i += 3; }
+    }
+
+    Scene scene = LoadOBJFromFile(g_filename);
+    const unsigned n = (unsigned)scene.triangles.size();
+    const bool hybrid = args.build_type == kHybrid;
+    const unsigned root_index = hybrid ? n * 2 + 1 : 0;   // main.cu:222
+    const unsigned root_count = 2;                        // main.cu:223 (bottom-up / hybrid)
+
+    MemoryBuffer<Camera> camera(1);
+    memset(camera.data(), 0, sizeof(Camera));
+    InitialiseCamera(camera[0], scene.aabb);
+    if (have_pos) camera[0].position = pos;
+    if (have_yaw) camera[0].yaw = yaw;
+    if (have_pitch) camera[0].pitch = pitch;
+    UpdateCamera(camera[0]);
+    camera.toDevice();
+
+    // frame 0 of Display(): the four device buffers, upload, build, read back, count, verify (main.cu:226-259)
+    BuildInput in{};
+    in.num_triangles = n;
+    check(hipMalloc((void**)&in.triangles_in, sizeof(Triangle) * (n ? n : 1)));
+    check(hipMalloc((void**)&in.triangles_out, sizeof(TrianglePair) * (size_t)(n ? n : 1) * 2));
+    check(hipMalloc(&in.scratch, BuMemoryRequirements(n)));
+    check(hipMalloc((void**)&in.nodes_out, rt_nodes_bytes(n)));
+    if (n) check(hipMemcpy(in.triangles_in, scene.triangles.data(), sizeof(Triangle) * n, hipMemcpyHostToDevice));
+
+    hipEvent_t e0, e1;
+    check(hipEventCreate(&e0));
+    check(hipEventCreate(&e1));
+    check(hipEventRecord(e0, nullptr));
+    RunBottomUpBuild(in, args, hybrid);
+    check(hipEventRecord(e1, nullptr));
+    check(hipEventSynchronize(e1));
+    float build_ms = 0;
+    check(hipEventElapsedTime(&build_ms, e0, e1));
+    printf("RunBottomUpBuild time elapsed: %fms\n", build_ms);
+
+    std::vector<Node> nodes((size_t)(n ? n : 1) * 4);
+    check(hipMemcpy(nodes.data(), in.nodes_out, sizeof(Node) * nodes.size(), hipMemcpyDeviceToHost));
+    const HierarchyStats hs = CountNodes(nodes.data(), root_index, root_count);
+    printf("Hierarchy Stats:\n  num nodes: %d\n  num tree nodes: %d\n  num leaf nodes: %d\n", hs.numNodes, hs.numTreeNodes, hs.numLeafNodes);
+    const int bad = VerifyHierarchy(nodes.data(), root_index, root_count);
+
+    // scene attributes / materials to the device (Scene::CopyToDevice, main.cu:421-456, PODs instead of std::string structs)
+    Attributes* d_attr = nullptr;
+    rt_material* d_mat = nullptr;
+    std::vector<rt_material> mats;
+    for (const Material& m : scene.library.materials) mats.push_back(m.pod());
+    if (n) {
+        check(hipMalloc((void**)&d_attr, sizeof(Attributes) * n));
+        check(hipMemcpy(d_attr, scene.attributes.data(), sizeof(Attributes) * n, hipMemcpyHostToDevice));
+    }
+    if (!mats.empty()) {
+        check(hipMalloc((void**)&d_mat, sizeof(rt_material) * mats.size()));
+        check(hipMemcpy(d_mat, mats.data(), sizeof(rt_material) * mats.size(), hipMemcpyHostToDevice));
+    }
+    DeviceSceneView view;
+    view.attributes = d_attr;
+    view.materials = d_mat;
+    view.num_attributes = n;
+    view.num_materials = (uint32_t)mats.size();
+    view.light = scene.light;
+
+    MemoryBuffer<uint8_t> frame((size_t)width * height * 4);
+    MemoryBuffer<uint64_t> num_tests(4);
+    for (int k = 0; k < 4; k++) num_tests[k] = 0;
+    num_tests.toDevice();
+    float trace_ms = 0;
+    for (int f = 0; f < frames; f++) {
+        check(hipEventRecord(e0, nullptr));
+        Trace(in.triangles_out, in.nodes_out, frame.gpu(), width, height, camera.gpu(), root_index, root_count, args.render_type,
+              view, f == 0 ? num_tests.gpu() : nullptr, 0, (unsigned)height, spp);
+        check(hipEventRecord(e1, nullptr));
+        check(hipEventSynchronize(e1));
+        check(hipEventElapsedTime(&trace_ms, e0, e1));
+        if (f == 0) {
+            printf("TraceRays time elapsed: %fms\n", trace_ms);
+            num_tests.toHost();
+            printf("TraceRays number of tests %llu\n", (unsigned long long)num_tests[0]);   // main.cu:180-183
+        }
+    }
+    if (frames > 1) printf("last frame: %fms = %.1f Mrays/s\n", trace_ms, (double)width * height * spp / trace_ms / 1e3);
+    if (!out.empty()) {
+        frame.toHost();
+        std::ofstream os(out, std::ios::binary);
+        os << "P6\n" << width << " " << height << "\n255\n";
+        for (size_t p = 0; p < (size_t)width * height; p++) os.write(reinterpret_cast<const char*>(&frame[p * 4]), 3);
+        printf("wrote %s\n", out.c_str());
+    }
+    (void)hipFree(in.triangles_in); (void)hipFree(in.triangles_out); (void)hipFree(in.scratch); (void)hipFree(in.nodes_out);
+    if (d_attr) (void)hipFree(d_attr);
+    if (d_mat) (void)hipFree(d_mat);
+    return bad ? 1 : 0;
+}

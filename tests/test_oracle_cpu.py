@@ -1,0 +1,211 @@
+"""CPU tests (no GPU): the oracle against its frozen golden vectors, against independent numpy restatements, and
+against the reference's own hierarchy checker compiled from the reference tree (oracle/_ref)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return json.load(open(os.path.join(GOLD, "golden.json")))
+
+
+@pytest.fixture(scope="module")
+def fixtures():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLD, "make_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.fixture_scenes()
+
+
+@pytest.mark.parametrize("name", ["cornell34", "grid24", "soup2048", "flat12"])
+def test_oracle_matches_golden(name, golden, fixtures, ora):
+    tris, cam, w, h, at, mats, light = fixtures[name]
+    g = golden[name]
+    assert cam.tobytes().hex() == g["camera_hex"], "camera construction drifted (numpy float32 sin/cos)"
+    b = ora.build_bvh(tris)
+    assert b["n"] == g["n"]
+    assert [int(x) for x in b["aabb"]] == g["aabb_ordered"]
+    assert sha(b["codes"]) == g["codes_sha256"] and sha(b["indices"]) == g["indices_sha256"]
+    assert sha(b["nodes"]) == g["nodes_sha256"] and sha(b["leaves"]) == g["leaves_sha256"]
+    assert list(ora.count_nodes(b["nodes"], 0, 2)) == g["count_nodes"]
+    for rtype, fr in g["frames"].items():
+        img, cnt = ora.trace(b["leaves"], b["nodes"], 0, 2, cam, w, h, render_type=int(rtype), attributes=at,
+                             materials=mats, light=light)
+        assert (int(cnt[0]), int(cnt[1]), int(cnt[2])) == (fr["box_tests"], fr["tri_tests"], fr["max_stack"])
+        if int(rtype) != 5:      # kDiffuse goes through libm pow(): allowed to move by 1 LSB between libms
+            assert sha(img) == fr["sha256"], f"render type {rtype}"
+    if name == "cornell34":
+        z = np.load(os.path.join(GOLD, "cornell34_bvh.npz"))
+        assert (b["nodes"].view(np.uint32).reshape(-1, 8) == z["nodes"]).all()
+        assert (b["leaves"].view(np.uint32).reshape(-1, 16) == z["leaves"]).all()
+        for rtype in (0, 5):
+            exp = np.load(os.path.join(GOLD, f"cornell34_frame_r{rtype}.npz"))["rgba"]
+            img, _ = ora.trace(b["leaves"], b["nodes"], 0, 2, cam, w, h, render_type=rtype, attributes=at,
+                               materials=mats, light=light)
+            assert np.abs(img.astype(int) - exp.astype(int)).max() <= (1 if rtype == 5 else 0)
+
+
+def test_node_count_identities_and_reference_checker(ora, scenes):
+    """L leaves -> CountNodes = (2L-2, L, L-2); VerifyHierarchy silent.  Both through the oracle's
+    restatement and through the reference's Utilities.cpp compiled unmodified (oracle/_ref), and both must flag a
+    corrupted box on the same node."""
+    for tris in (scenes.grid_mesh(24, 1), scenes.soup(3000, 5), scenes.flat_mesh(9, 2)):
+        b = ora.build_bvh(tris)
+        n = b["n"]
+        assert ora.count_nodes(b["nodes"], 0, 2) == (2 * n - 2, n, n - 2)
+        assert ora.verify_hierarchy(b["nodes"], 0, 2) == 0
+        bad = b["nodes"].copy()
+        bad["max"][10, 1] += 1.0
+        assert ora.verify_hierarchy(bad, 0, 2) == 1
+        if ora.ref_available():
+            assert ora.ref_count_nodes(b["nodes"], 0, 2) == (2 * n - 2, n, n - 2)
+            assert ora.ref_verify_hierarchy(b["nodes"], 0, 2) == ""
+            parent = int(b["nodes"]["w12"][10] & 0x1FFFFFFF)
+            assert f"failed on index {parent}\n" in ora.ref_verify_hierarchy(bad, 0, 2)
+    if not ora.ref_available():
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine): restatement checked only")
+
+
+def _expand_bits(v):
+    v = (v * np.uint32(0x00010001)) & np.uint32(0xFF0000FF)
+    v = (v * np.uint32(0x00000101)) & np.uint32(0x0F00F00F)
+    v = (v * np.uint32(0x00000011)) & np.uint32(0xC30C30C3)
+    v = (v * np.uint32(0x00000005)) & np.uint32(0x49249249)
+    return v
+
+
+def test_morton_codes_against_numpy(ora, scenes):
+    """Independent float32 numpy restatement of GenerateMortonCodes (BottomUpBuilder.cu:12-32,98-115)."""
+    for tris in (scenes.grid_mesh(17, 3), scenes.soup(5000, 1), scenes.flat_mesh(8, 1)):
+        aabb = ora.scene_aabb(tris)
+        t = tris.reshape(-1, 3, 3).astype(np.float32)
+        lo, hi = ora.ordered_to_float(aabb[:3]), ora.ordered_to_float(aabb[3:])
+        assert (lo == t.reshape(-1, 3).min(0)).all() and (hi == t.reshape(-1, 3).max(0)).all()
+        with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
+            c = ((t[:, 0] + t[:, 1]) + t[:, 2]) / np.float32(3.0)
+            c = (c - lo) / (hi - lo)
+            c = np.fmax(np.float32(0), np.fmin(c, np.float32(1)))          # clamp with minNum/maxNum: NaN -> 1
+            q = np.fmin(np.fmax(c * np.float32(1024), np.float32(0)), np.float32(1023)).astype(np.uint32)
+            exp = _expand_bits(q[:, 0]) * np.uint32(4) + _expand_bits(q[:, 1]) * np.uint32(2) + _expand_bits(q[:, 2])
+        codes, vals = ora.morton_codes(tris, aabb)
+        assert (codes == exp).all() and (vals == np.arange(t.shape[0])).all()
+
+
+def test_radix_sort_is_stable_sort(ora):
+    rng = np.random.default_rng(5)
+    for n, bits in ((1, 32), (2, 1), (1000, 30), (65537, 8), (300000, 32)):
+        k = rng.integers(0, 2 ** bits, size=n, dtype=np.uint64).astype(np.uint32)
+        v = np.arange(n, dtype=np.uint32)
+        for threads in (1, 3, 8):
+            ora.set_threads(threads)
+            sk, sv = ora.radix_sort(k, v)
+            o = np.argsort(k, kind="stable")
+            assert (sk == k[o]).all() and (sv == v[o]).all()
+    ora.set_threads(4)
+
+
+def _radix_tree_bruteforce(codes):
+    """Binary radix tree over the keys (code_i, i) by recursive splitting at the highest differing bit, numbered the
+    Karras way (left child of a split at s is internal node s, right child s+1; root 0)."""
+    n = len(codes)
+    key = (codes.astype(np.uint64) << np.uint64(32)) | np.arange(n, dtype=np.uint64)
+    out = {}
+    stack = [(0, 0, n - 1)]
+    while stack:
+        idx, f, l = stack.pop()
+        diff = int(key[f]) ^ int(key[l])
+        bit = diff.bit_length() - 1
+        split = f + int(np.searchsorted((key[f:l + 1] >> np.uint64(bit)) & np.uint64(1), 1)) - 1
+        out[idx] = (f, l, split)
+        if split > f:
+            stack.append((split, f, split))
+        if split + 1 < l:
+            stack.append((split + 1, split + 1, l))
+    return out
+
+
+def test_hierarchy_against_bruteforce_radix_tree(ora, scenes):
+    """GenerateHierarchy (Karras searches) restated in the oracle vs a brute-force radix tree: same children, types,
+    parents and leaf ranges -- including duplicate codes (index tie-break)."""
+    for tris in (scenes.grid_mesh(9, 1), scenes.soup(700, 3, dup_fraction=0.6), scenes.soup(64, 9, dup_fraction=0.0)):
+        b = ora.build_bvh(tris)
+        nd, n = b["nodes"], b["n"]
+        tree = _radix_tree_bruteforce(b["codes"])
+        assert len(tree) == n - 1
+        for idx, (f, l, s) in tree.items():
+            for side, (cf, cl, cidx) in enumerate(((f, s, s), (s + 1, l, s + 1))):
+                slot = nd[2 * idx + side]
+                child, ctype, count = int(slot["w28"] & 0x1FFFFFFF), int(slot["w28"] >> 29), int(slot["w12"] >> 29)
+                if cf == cl:
+                    assert (child, ctype, count) == (cf, 2, 1)
+                else:
+                    assert (child, ctype, count) == (2 * cidx, 1, 2)
+                    assert int(nd[2 * cidx]["w12"] & 0x1FFFFFFF) == 2 * idx + side
+                    assert int(nd[2 * cidx + 1]["w12"] & 0x1FFFFFFF) == 2 * idx + side
+                leaves = b["leaves"][cf:cl + 1]
+                pts = np.concatenate([leaves["v0"], leaves["v1"], leaves["v2"]])
+                assert (slot["min"] == pts.min(0)).all() and (slot["max"] == pts.max(0)).all()
+
+
+def test_trace_depth_against_bruteforce(ora, scenes):
+    """kDepth through the BVH vs intersecting every triangle (float64-free restatement of Moller-Trumbore in float32
+    numpy): the nearest t is a per-triangle quantity, so the frames must agree except where a ray grazes a box face
+    within rounding (counted, must be rare)."""
+    tris = scenes.soup(300, 4, dup_fraction=0.1, size=0.25)
+    b = ora.build_bvh(tris)
+    lo, hi = ora.ordered_to_float(b["aabb"][:3]), ora.ordered_to_float(b["aabb"][3:])
+    cam = scenes.camera_for_box(lo, hi)
+    w, h = 96, 64
+    img, _ = ora.trace(b["leaves"], b["nodes"], 0, 2, cam, w, h)
+    c = cam[0]
+    f32 = np.float32
+    xs, ys = np.meshgrid(np.arange(w, dtype=f32), np.arange(h, dtype=f32))
+    ndcx = f32(2) * ((xs + f32(0.5)) / f32(w)) - f32(1)
+    ndcy = f32(2) * ((ys + f32(0.5)) / f32(h)) - f32(1)
+    p = (ndcx[..., None] * c["u"] + ndcy[..., None] * c["v"]) + f32(1) * c["w"]
+    d = p * (f32(1) / np.sqrt((p[..., 0] * p[..., 0] + p[..., 1] * p[..., 1]) + p[..., 2] * p[..., 2], dtype=f32))[..., None]
+    o = c["position"]
+    tmax = np.full((h, w), c["max_depth"], f32)
+    hit = np.zeros((h, w), bool)
+    t3 = tris.reshape(-1, 3, 3)
+
+    def cross(a, bb):
+        return np.stack([a[..., 1] * bb[..., 2] - a[..., 2] * bb[..., 1], a[..., 2] * bb[..., 0] - a[..., 0] * bb[..., 2],
+                         a[..., 0] * bb[..., 1] - a[..., 1] * bb[..., 0]], -1).astype(f32)
+
+    def dot(a, bb):
+        return ((a[..., 0] * bb[..., 0] + a[..., 1] * bb[..., 1]) + a[..., 2] * bb[..., 2]).astype(f32)
+
+    with np.errstate(all="ignore"):
+        for v0, v1, v2 in t3:
+            e1, e2 = (v1 - v0).astype(f32), (v2 - v0).astype(f32)
+            hh = cross(d, np.broadcast_to(e2, d.shape))
+            a = dot(np.broadcast_to(e1, d.shape), hh)
+            ok = ~((a > f32(-1e-9)) & (a < f32(1e-9)))
+            f = f32(1) / a
+            s = np.broadcast_to((o - v0).astype(f32), d.shape)
+            u = f * dot(s, hh)
+            ok &= ~((u < 0) | (u > 1))
+            q = cross(s, np.broadcast_to(e1, d.shape))
+            v = f * dot(d, q)
+            ok &= ~((v < 0) | ((u + v) > 1))
+            t = f * dot(np.broadcast_to(e2, d.shape), q)
+            ok &= ~((t < f32(0.00001)) | (t > tmax))
+            tmax = np.where(ok, t, tmax)
+            hit |= ok
+    exp = (np.fmin(f32(1), np.where(hit, tmax, f32(0)) / c["max_depth"]) * f32(255)).astype(np.uint8)
+    mism = int((exp != img[..., 0]).sum())
+    assert mism <= 3, f"{mism} pixels differ between BVH traversal and brute force"
+    assert hit.sum() > 200
