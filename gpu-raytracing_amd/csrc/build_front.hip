@@ -11,30 +11,35 @@ namespace rt {
 
 // ---------------------------------------------------------------------------------------------
 // Scene AABB.  Flat element e of the triangle array belongs to axis e % 3.  A thread strides by
-// gridDim.x*256 float4's, and the grid is a multiple of 3 blocks, so (float4 index) % 3 -- the axis
-// of the first element of every float4 a thread loads -- is constant per thread: min/max are kept in
+// gridDim.x*1024 float4's, and the grid is a multiple of 3 blocks, so (float4 index) % 3 -- the axis
+// of the first element of every float4 a thread loads -- is constant per thread (1024 % 3 == 1): min/max are kept in
 // that rotated frame and un-rotated once at the end.  Everything is folded in the ordered-int
 // domain (DeviceUtils.cuh:3-13), wave-reduced, block-reduced through LDS and finished with 6 integer
 // atomics per BLOCK (exact, order independent).
-__global__ __launch_bounds__(256) void scene_aabb_kernel(const float* __restrict__ f, uint64_t nfloats,
-                                                         int* __restrict__ aabb)
+__global__ __launch_bounds__(1024) void scene_aabb_kernel(const float* __restrict__ f, uint64_t nfloats,
+                                                          int* __restrict__ aabb)
 {
     const uint64_t nvec = nfloats >> 2;
-    const uint64_t stride = (uint64_t)gridDim.x * 256;
-    uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * 1024;
+    uint64_t q = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
     const int r = (int)(q % 3);  // axis of element 0 of every float4 of this thread
 
     int lo0 = 0x7f7fffff, lo1 = 0x7f7fffff, lo2 = 0x7f7fffff;
     int hi0 = (int)0x80800000, hi1 = (int)0x80800000, hi2 = (int)0x80800000;
     const float4* f4 = reinterpret_cast<const float4*>(f);
-    for (; q < nvec; q += stride) {
-        float4 v = f4[q];
-        int a = float_to_ordered_int(v.x), b = float_to_ordered_int(v.y);
-        int c = float_to_ordered_int(v.z), d = float_to_ordered_int(v.w);
+    auto fold = [&](const float4& v) {
+        const int a = float_to_ordered_int(v.x), b = float_to_ordered_int(v.y);
+        const int c = float_to_ordered_int(v.z), d = float_to_ordered_int(v.w);
         lo0 = min(lo0, min(a, d)); hi0 = max(hi0, max(a, d));  // elements 0 and 3 share an axis
         lo1 = min(lo1, b);         hi1 = max(hi1, b);
         lo2 = min(lo2, c);         hi2 = max(hi2, c);
+    };
+    // 4 independent 16-byte loads in flight per thread
+    for (; q + 3 * stride < nvec; q += 4 * stride) {
+        const float4 v0 = f4[q], v1 = f4[q + stride], v2 = f4[q + 2 * stride], v3 = f4[q + 3 * stride];
+        fold(v0); fold(v1); fold(v2); fold(v3);
     }
+    for (; q < nvec; q += stride) fold(f4[q]);
     // un-rotate: frame slot s is axis (r + s) % 3
     int lo[3], hi[3];
     lo[0] = r == 0 ? lo0 : (r == 1 ? lo2 : lo1);
@@ -52,7 +57,7 @@ __global__ __launch_bounds__(256) void scene_aabb_kernel(const float* __restrict
             hi[ax] = max(hi[ax], v);
         }
     }
-    __shared__ int red[4][6];
+    __shared__ int red[16][6];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -61,15 +66,10 @@ __global__ __launch_bounds__(256) void scene_aabb_kernel(const float* __restrict
     }
     __syncthreads();
     if (threadIdx.x < 6) {
-        int k = threadIdx.x;
+        const int k = threadIdx.x;
         int v = red[0][k];
-        if (k < 3) {
-            v = min(min(v, red[1][k]), min(red[2][k], red[3][k]));
-            atomicMin(&aabb[k], v);
-        } else {
-            v = max(max(v, red[1][k]), max(red[2][k], red[3][k]));
-            atomicMax(&aabb[k], v);
-        }
+        for (int w = 1; w < 16; w++) v = k < 3 ? min(v, red[w][k]) : max(v, red[w][k]);
+        if (k < 3) atomicMin(&aabb[k], v); else atomicMax(&aabb[k], v);   // 6 atomics per workgroup, <= 255 workgroups
     }
 }
 
@@ -154,10 +154,11 @@ hipError_t launch_scene_aabb(const rt_triangle* tris, uint32_t n, int* aabb, hip
 {
     if (n == 0) return hipSuccess;
     const uint64_t nfloats = (uint64_t)n * 9;
-    uint64_t want = (nfloats / 4 + 255) / 256;              // one float4 per thread
-    uint32_t blocks = (uint32_t)(want < 3 ? 3 : (want > 1536 ? 1536 : want));
-    blocks = (blocks + 2) / 3 * 3;                           // multiple of 3 (see kernel comment)
-    scene_aabb_kernel<<<blocks, 256, 0, st>>>(reinterpret_cast<const float*>(tris), nfloats, aabb);
+    // ~4 float4 per thread, at most 255 workgroups of 1024 (one per CU): few same-address atomics at the end
+    uint64_t want = (nfloats / 16 + 1023) / 1024;
+    uint32_t blocks = (uint32_t)(want < 3 ? 3 : (want > 255 ? 255 : want));
+    blocks = blocks / 3 * 3;                                 // multiple of 3 (see kernel comment)
+    scene_aabb_kernel<<<blocks, 1024, 0, st>>>(reinterpret_cast<const float*>(tris), nfloats, aabb);
     return hipGetLastError();
 }
 

@@ -30,8 +30,7 @@ __device__ __forceinline__ uint64_t match_digit8(uint32_t d, bool valid)
 
 __global__ __launch_bounds__(256) void sort_upsweep_kernel(const uint32_t* __restrict__ keys, uint32_t n,
                                                            uint32_t shift, uint32_t num_tiles,
-                                                           uint32_t* __restrict__ hist,
-                                                           uint32_t* __restrict__ digit_total)
+                                                           uint32_t* __restrict__ hist)
 {
     __shared__ uint32_t h[kRadix];
     h[threadIdx.x] = 0;
@@ -54,22 +53,18 @@ __global__ __launch_bounds__(256) void sort_upsweep_kernel(const uint32_t* __res
         if (valid && lane == __ffsll((unsigned long long)m) - 1) atomicAdd(&h[d], (uint32_t)__popcll(m));
     }
     __syncthreads();
-    const uint32_t c = h[threadIdx.x];
-    hist[(size_t)threadIdx.x * num_tiles + tile] = c;
-    if (c) atomicAdd(&digit_total[threadIdx.x], c);
+    hist[(size_t)threadIdx.x * num_tiles + tile] = h[threadIdx.x];   // no global atomics anywhere in the sort
 }
 
-// one workgroup per digit d: offs[d][t] = sum(digit_total[0..d)) + sum(hist[d][0..t))
-__global__ __launch_bounds__(256) void sort_scan_kernel(const uint32_t* __restrict__ hist,
-                                                        const uint32_t* __restrict__ digit_total,
-                                                        uint32_t num_tiles, uint32_t* __restrict__ offs)
+// one workgroup per digit d: offs[d][t] = sum(hist[d][0..t)) (position inside the digit's output run),
+// totals[d] = sum over all tiles.  The digit bases (exclusive scan of totals) are formed by each downsweep
+// workgroup in its prologue: 256 values, one block scan -- cheaper than a launch or 256 same-address atomics per tile.
+__global__ __launch_bounds__(256) void sort_scan_kernel(const uint32_t* __restrict__ hist, uint32_t num_tiles,
+                                                        uint32_t* __restrict__ offs, uint32_t* __restrict__ totals)
 {
     __shared__ uint32_t ws[8];
     const uint32_t d = blockIdx.x;
-    uint32_t total;
-    uint32_t mine = threadIdx.x < d ? digit_total[threadIdx.x] : 0u;
-    block_excl_scan_u32<256>(mine, ws, &total);
-    uint32_t running = total;
+    uint32_t running = 0;
     const uint32_t* hrow = hist + (size_t)d * num_tiles;
     uint32_t* orow = offs + (size_t)d * num_tiles;
     for (uint32_t c = 0; c < num_tiles; c += 256) {
@@ -80,6 +75,7 @@ __global__ __launch_bounds__(256) void sort_scan_kernel(const uint32_t* __restri
         if (t < num_tiles) orow[t] = running + ex;
         running += chunk;
     }
+    if (threadIdx.x == 0) totals[d] = running;
 }
 
 __global__ __launch_bounds__(256) void sort_downsweep_kernel(const uint32_t* __restrict__ keys_in,
@@ -87,16 +83,21 @@ __global__ __launch_bounds__(256) void sort_downsweep_kernel(const uint32_t* __r
                                                              uint32_t* __restrict__ keys_out,
                                                              uint32_t* __restrict__ vals_out, uint32_t n,
                                                              uint32_t shift, uint32_t num_tiles,
-                                                             const uint32_t* __restrict__ offs)
+                                                             const uint32_t* __restrict__ offs,
+                                                             const uint32_t* __restrict__ totals)
 {
-    // wave_hist[w][d]: first the running count of digit d inside wave w's chunk, later the global
-    // output position of wave w's first key with digit d.
+    // wave_hist[w][d]: first the running count of digit d inside wave w's chunk, later the position inside the
+    // tile (sorted by digit) of wave w's first key with digit d.
     __shared__ uint32_t wave_hist[4][kRadix];
+    __shared__ uint32_t glob[kRadix];            // global position of local position 0 of digit d's run (mod 2^32)
+    __shared__ uint32_t skey[kSortTile], sval[kSortTile];
+    __shared__ uint32_t ws[8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t tile = blockIdx.x;
 #pragma unroll
     for (int w = 0; w < 4; w++) wave_hist[w][threadIdx.x] = 0;
-    __syncthreads();
+    uint32_t dummy;
+    const uint32_t digit_base = block_excl_scan_u32<256>(totals[threadIdx.x], ws, &dummy);  // ends with a barrier
 
     // wave w owns keys [base + w*1024, base + (w+1)*1024) in rounds of 64 consecutive keys, so
     // (wave, round, lane) order IS input order: stability.
@@ -126,30 +127,41 @@ __global__ __launch_bounds__(256) void sort_downsweep_kernel(const uint32_t* __r
     __syncthreads();
     {
         const uint32_t d = threadIdx.x;
-        uint32_t run = offs[(size_t)d * num_tiles + tile];
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-            uint32_t c = wave_hist[w][d];
-            wave_hist[w][d] = run;
-            run += c;
-        }
+        const uint32_t c0 = wave_hist[0][d], c1 = wave_hist[1][d], c2 = wave_hist[2][d], c3 = wave_hist[3][d];
+        uint32_t tile_total;
+        const uint32_t lstart = block_excl_scan_u32<256>(c0 + c1 + c2 + c3, ws, &tile_total);
+        wave_hist[0][d] = lstart;
+        wave_hist[1][d] = lstart + c0;
+        wave_hist[2][d] = lstart + c0 + c1;
+        wave_hist[3][d] = lstart + c0 + c1 + c2;
+        glob[d] = digit_base + offs[(size_t)d * num_tiles + tile] - lstart;
     }
     __syncthreads();
+    // local scatter: the tile sorted by digit in LDS, then written out in position order so that one store
+    // instruction covers contiguous runs (a tile holds 16 keys per digit on average: 64-byte runs)
 #pragma unroll
     for (int i = 0; i < (int)kSortItems; i++) {
         uint32_t idx = wbase + i * 64 + lane;
         if (idx < n) {
             const uint32_t d = (k[i] >> shift) & (kRadix - 1);
-            const uint32_t pos = wave_hist[wave][d] + rank[i];
-            keys_out[pos] = k[i];
-            vals_out[pos] = v[i];
+            const uint32_t lp = wave_hist[wave][d] + rank[i];
+            skey[lp] = k[i];
+            sval[lp] = v[i];
         }
     }
-}
-
-__global__ void sort_zero_totals_kernel(uint32_t* digit_total)
-{
-    digit_total[blockIdx.x * kRadix + threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t tbase = tile * kSortTile;
+    const uint32_t nvalid = min(kSortTile, n - tbase);
+#pragma unroll
+    for (int i = 0; i < (int)kSortItems; i++) {
+        const uint32_t j = i * kSortThreads + threadIdx.x;
+        if (j < nvalid) {
+            const uint32_t key = skey[j];
+            const uint32_t pos = glob[(key >> shift) & (kRadix - 1)] + j;
+            keys_out[pos] = key;
+            vals_out[pos] = sval[j];
+        }
+    }
 }
 
 SortScratch sort_scratch_layout(uint32_t n)
@@ -157,7 +169,7 @@ SortScratch sort_scratch_layout(uint32_t n)
     SortScratch s;
     const size_t tiles = sort_num_tiles(n) ? sort_num_tiles(n) : 1;
     size_t off = 0;
-    s.digit_total = off; off += (size_t)kSortPasses * kRadix * 4;
+    s.digit_total = off; off += (size_t)kSortPasses * kRadix * 4;   // totals[pass][digit], written by the scan kernel
     s.hist = off;        off += (tiles * kRadix * 4 + 255) / 256 * 256;
     s.offs = off;        off += (tiles * kRadix * 4 + 255) / 256 * 256;
     s.total = off;
@@ -175,14 +187,13 @@ hipError_t launch_radix_sort(uint32_t* keys, uint32_t* vals, uint32_t* tmp_keys,
     uint32_t* offs = reinterpret_cast<uint32_t*>(base + L.offs);
     const uint32_t tiles = sort_num_tiles(n);
 
-    sort_zero_totals_kernel<<<kSortPasses, kRadix, 0, st>>>(digit_total);
     uint32_t *sk = keys, *sv = vals, *dk = tmp_keys, *dv = tmp_vals;
     for (uint32_t pass = 0; pass < kSortPasses; pass++) {
         const uint32_t shift = pass * kRadixBits;
         uint32_t* dt = digit_total + pass * kRadix;
-        sort_upsweep_kernel<<<tiles, kSortThreads, 0, st>>>(sk, n, shift, tiles, hist, dt);
-        sort_scan_kernel<<<kRadix, 256, 0, st>>>(hist, dt, tiles, offs);
-        sort_downsweep_kernel<<<tiles, kSortThreads, 0, st>>>(sk, sv, dk, dv, n, shift, tiles, offs);
+        sort_upsweep_kernel<<<tiles, kSortThreads, 0, st>>>(sk, n, shift, tiles, hist);
+        sort_scan_kernel<<<kRadix, 256, 0, st>>>(hist, tiles, offs, dt);
+        sort_downsweep_kernel<<<tiles, kSortThreads, 0, st>>>(sk, sv, dk, dv, n, shift, tiles, offs, dt);
         uint32_t* x;
         x = sk; sk = dk; dk = x;
         x = sv; sv = dv; dv = x;

@@ -30,9 +30,12 @@ BuLayout bu_layout(uint32_t n)
 
 static inline int hip_rc(hipError_t e) { return e == hipSuccess ? RT_OK : RT_ERR_HIP_BASE - (int)e; }
 
-__global__ void clear_status_kernel(uint32_t* status)
+// one launch for the build's tiny initialisations: status words = 0 and the ordered-int "empty" scene box
+// (BuildWrapper.cu:288-303 does these with 6 memset / memcpy calls)
+__global__ void build_init_kernel(uint32_t* status, int* aabb)
 {
     if (threadIdx.x < 8) status[threadIdx.x] = 0;
+    if (threadIdx.x < 6) aabb[threadIdx.x] = threadIdx.x < 3 ? 0x7f7fffff : (int)0x80800000;
 }
 
 }  // namespace rt
@@ -108,8 +111,8 @@ int rt_run_bottom_up_build(const rt_build_input* input, const rt_arguments* args
     uint32_t* tmpk = reinterpret_cast<uint32_t*>(s + L.tmp_keys);
     uint32_t* tmpv = reinterpret_cast<uint32_t*>(s + L.tmp_vals);
 
-    clear_status_kernel<<<1, 64, 0, st>>>(status);
-    hipError_t e = launch_reset_aabb(p_aabb, st);
+    build_init_kernel<<<1, 64, 0, st>>>(status, p_aabb);
+    hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = launch_scene_aabb(input->triangles_in, n, p_aabb, st);
     if (e == hipSuccess) e = launch_morton(morton, sorted, input->triangles_in, p_aabb, n, st);
     if (e == hipSuccess) e = launch_radix_sort(morton, sorted, tmpk, tmpv, n, s + L.sort, st);
