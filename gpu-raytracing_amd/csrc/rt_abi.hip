@@ -96,7 +96,6 @@ int rt_run_bottom_up_build(const rt_build_input* input, const rt_arguments* args
     if (n && (!input->triangles_in || !input->triangles_out)) return RT_ERR_INVALID_ARGUMENT;
     if (n > (1u << 28)) return RT_ERR_TOO_LARGE;  // 2(n-1) slots must fit the 29-bit child field
     if (args && (args->enable_pairs || args->enable_splits)) return RT_ERR_UNSUPPORTED;
-    if (hybrid) return RT_ERR_UNSUPPORTED;  // not built yet
     if ((reinterpret_cast<uintptr_t>(input->scratch) & 255u) || (reinterpret_cast<uintptr_t>(input->triangles_in) & 15u) ||
         (reinterpret_cast<uintptr_t>(input->triangles_out) & 63u) || (reinterpret_cast<uintptr_t>(input->nodes_out) & 63u))
         return RT_ERR_INVALID_ARGUMENT;
@@ -119,6 +118,7 @@ int rt_run_bottom_up_build(const rt_build_input* input, const rt_arguments* args
     if (e == hipSuccess)
         e = launch_lbvh_levels(input->triangles_in, morton, sorted, n, input->triangles_out, input->nodes_out,
                                s + L.levels, status, st);
+    if (e == hipSuccess && hybrid) e = launch_hybrid_top(input->nodes_out, p_aabb, n, st);   // BuildWrapper.cu:350-361
     return hip_rc(e);
 }
 
@@ -151,7 +151,7 @@ const char* rt_error_string(int code)
     switch (code) {
     case RT_OK: return "ok";
     case RT_ERR_INVALID_ARGUMENT: return "invalid argument";
-    case RT_ERR_UNSUPPORTED: return "unsupported option (pairs / splits / SAH / hybrid / textured render type)";
+    case RT_ERR_UNSUPPORTED: return "unsupported option (pairs / splits / SAH / textured render type)";
     case RT_ERR_TOO_LARGE: return "too many triangles for the 29-bit node index";
     default: break;
     }

@@ -70,6 +70,8 @@ hipError_t launch_lbvh_levels(const rt_triangle* tris, const uint32_t* codes, co
                               uint32_t n, rt_triangle_pair* leaves, rt_node* nodes, void* level_scratch,
                               uint32_t* status, hipStream_t st);
 
+hipError_t launch_hybrid_top(rt_node* nodes, const int* aabb_ordered, uint32_t n, hipStream_t st);
+
 struct TraceLaunch {
     rt_accel as;
     rt_scene scene;

@@ -100,7 +100,7 @@ typedef struct rt_scene {
 enum {
     RT_OK = 0,
     RT_ERR_INVALID_ARGUMENT = -1,
-    RT_ERR_UNSUPPORTED = -2,       /* pairs / splits / SAH / textured render types: SURVEY 8(f) "next" rows */
+    RT_ERR_UNSUPPORTED = -2,       /* pairs / splits / SAH builder / textured render types: SURVEY 8(f) "next" rows */
     RT_ERR_TOO_LARGE = -3,         /* n exceeds the 29-bit child index of Node (Common.cuh:152-159) */
     RT_ERR_HIP_BASE = -1000        /* -(hipError_t) + RT_ERR_HIP_BASE */
 };
@@ -114,7 +114,8 @@ size_t rt_nodes_bytes(uint32_t num_triangles);
 
 /* replaces RunBottomUpBuild (BuildWrapper.cu:253-362).  hybrid != 0 additionally builds the SAH top
  * tree above the 8-level-deep LBVH sub-roots (ExtractDepth + SharedTaskBuild, BuildWrapper.cu:350-361);
- * trace root is then (2n+1, 2) instead of (0, 2) (main.cu:222-223). */
+ * trace root is then (2n+1, 2) instead of (0, 2) (main.cu:222-223).  The top tree is built deterministically
+ * (the reference's numbering depends on atomic arrival order); it occupies slots [2n, 2n + 2*256 + 2). */
 int rt_run_bottom_up_build(const rt_build_input* input, const rt_arguments* args, int hybrid, void* stream);
 
 /* Where the build's intermediates live inside `scratch` (for parity tests and callers that want the

@@ -41,6 +41,8 @@ def lib() -> ctypes.CDLL:
         L.ora_morton_codes.argtypes = [vp, u32, vp, vp, vp]
         L.ora_radix_sort.argtypes = [vp, vp, vp, vp, u32]
         L.ora_build.argtypes = [vp, u32, vp, vp, vp, vp, vp]
+        L.ora_build_hybrid_top.argtypes = [vp, u32, vp, vp]
+        L.ora_build_hybrid_top.restype = u32
         L.ora_count_nodes.argtypes = [vp, u32, u32, vp]
         L.ora_verify_hierarchy.argtypes = [vp, u32, u32]
         L.ora_verify_hierarchy.restype = ctypes.c_int
@@ -96,6 +98,19 @@ def build_bvh(tris: np.ndarray) -> dict:
     aabb = np.zeros(6, np.int32)
     lib().ora_build(_p(t), n, _p(nodes), _p(leaves), _p(codes), _p(idx), _p(aabb))
     return dict(nodes=nodes, leaves=leaves[:n], codes=codes[:n], indices=idx[:n], aabb=aabb, n=n)
+
+
+def build_hybrid(tris: np.ndarray) -> dict:
+    """RunBottomUpBuild(hybrid=true): the LBVH plus the deterministic SAH top tree at slots >= 2L.
+    Trace root = (root, 2) with root = 2L+1 (main.cu:222-223)."""
+    b = build_bvh(tris)
+    n = b["n"]
+    nodes = np.zeros(2 * max(n, 1) + 2 * 256 + 8, dtype=NODE)
+    nodes[:b["nodes"].shape[0]] = b["nodes"]
+    sub = np.zeros(256, np.uint32)
+    k = lib().ora_build_hybrid_top(_p(nodes), n, _p(b["aabb"]), _p(sub))
+    b.update(nodes=nodes, subroots=sub[:k], root=max(2 * n, 2) + 1)
+    return b
 
 
 def count_nodes(nodes: np.ndarray, root: int, count: int) -> tuple:

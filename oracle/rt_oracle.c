@@ -342,6 +342,189 @@ void ora_build(const ora_triangle* tris, uint32_t n, ora_node* nodes, ora_triang
     free(codes); free(vals); free(t1); free(t2);
 }
 
+/* ================================================================== hybrid top tree
+ * ExtractDepth (BottomUpBuilder.cu:314-371): thread tid walks from pair 0 following bit d of tid at level d
+ * (bit set -> the child of slot cur, bit clear -> the child of slot cur+1), 8 levels; a pair with a Tri slot stops
+ * the walk and is emitted once (by the thread whose remaining high bits are zero). */
+static uint32_t extract_depth(const ora_node* nodes, uint32_t* subroots, float (*boxes)[6])
+{
+    uint32_t k = 0;
+    for (uint32_t tid = 0; tid < 256; tid++) {
+        uint32_t cur = 0, d = 0;
+        int emit = 1;
+        for (; d < 8; d++) {
+            if ((nodes[cur].w28 >> 29) == ORA_TYPE_TRI || (nodes[cur + 1].w28 >> 29) == ORA_TYPE_TRI ||
+                (nodes[cur].w28 >> 29) == ORA_TYPE_NONE || (nodes[cur + 1].w28 >> 29) == ORA_TYPE_NONE) {
+                emit = (tid >> d) == 0;   /* (None only occurs in the n < 2 trees this build defines, Q8) */
+                break;
+            }
+            uint32_t direction = (tid >> d) & 1u;
+            cur = (direction ? nodes[cur].w28 : nodes[cur + 1].w28) & NODE_PARENT_MASK;
+        }
+        if (!emit) continue;
+        subroots[k] = cur;
+        ora_f3 lo = nodes[cur].min, hi = nodes[cur].max;
+        if ((nodes[cur + 1].w28 >> 29) != ORA_TYPE_NONE) {
+            lo = min3(lo, nodes[cur + 1].min);
+            hi = max3(hi, nodes[cur + 1].max);
+        }
+        boxes[k][0] = lo.x; boxes[k][1] = lo.y; boxes[k][2] = lo.z;
+        boxes[k][3] = hi.x; boxes[k][4] = hi.y; boxes[k][5] = hi.z;
+        k++;
+    }
+    return k;
+}
+
+static inline float box_sa(const float* b)  /* Common.cuh:293-297 sa() */
+{
+    float lx = b[3] - b[0], ly = b[4] - b[1], lz = b[5] - b[2];
+    return 2.0f * (lx * ly + lx * lz + ly * lz);
+}
+static inline void box_reset(float* b) { b[0] = b[1] = b[2] = 3.402823466e+38f; b[3] = b[4] = b[5] = -3.402823466e+38f; }
+static inline void box_grow(float* b, const float* o)
+{
+    for (int k = 0; k < 3; k++) { b[k] = fminf(b[k], o[k]); b[3 + k] = fmaxf(b[3 + k], o[3 + k]); }
+}
+static inline void box_grow_pt(float* b, const float* c)
+{
+    for (int k = 0; k < 3; k++) { b[k] = fminf(b[k], c[k]); b[3 + k] = fmaxf(b[3 + k], c[k]); }
+}
+static inline void put_node(ora_node* n, const float* b, uint32_t child, uint32_t count, uint32_t type)
+{
+    n->min = f3(b[0], b[1], b[2]);
+    n->max = f3(b[3], b[4], b[5]);
+    n->w12 = count << 29;                      /* parent is never written by SharedTaskBuild: defined as 0 */
+    n->w28 = (child & NODE_PARENT_MASK) | (type << 29);
+}
+
+typedef struct { float c[6], p[6]; uint32_t start, end, parent_idx, buf; } top_task;
+
+uint32_t ora_build_hybrid_top(ora_node* nodes, uint32_t L, const int32_t aabb[6], uint32_t* subroots_out)
+{
+    uint32_t subroots[256];
+    float boxes[256][6];
+    const uint32_t K = extract_depth(nodes, subroots, boxes);
+    if (subroots_out) memcpy(subroots_out, subroots, K * 4);
+    const uint32_t slots = 2 * (L > 1 ? L - 1 : 1);   /* LBVH slots in use; the reference writes at 2L (BuildWrapper.cu:360) */
+    uint32_t base = 2 * L;
+    if (base < slots) base = slots;
+    uint32_t write_index = base;
+    top_task* queue = (top_task*)malloc(sizeof(top_task) * 1024);
+    uint32_t qh = 0, qt = 0;
+    uint32_t ids[2][256];
+    for (uint32_t i = 0; i < 256; i++) ids[0][i] = i;     /* tmp_ids = 0..511 (BuildWrapper.cu:292-293,303) */
+
+    top_task root;
+    box_reset(root.c);
+    for (uint32_t i = 0; i < K; i++) box_grow(root.c, boxes[i]);   /* "centroid" bounds = union of the BOXES (:341-346) */
+    for (int k = 0; k < 6; k++) root.p[k] = ora_ordered_int_to_float(aabb[k]);
+    root.start = 0; root.end = K; root.parent_idx = write_index++; root.buf = 0;
+    if (K == 1) {
+        /* the reference writes the single leaf INTO slot 2L and then traces from (2L+1, 2): garbage.  Defined
+         * here: 2L = Box{2L+1, count 1}, 2L+1 = the leaf descriptor, 2L+2 = None. */
+        put_node(&nodes[base], root.p, base + 1, 1, ORA_TYPE_BOX);
+        put_node(&nodes[base + 1], boxes[0], subroots[0], 2, ORA_TYPE_BOX);
+        memset(&nodes[base + 2], 0, sizeof(ora_node));
+        free(queue);
+        return K;
+    }
+    queue[qt++] = root;
+    while (qh < qt) {
+        top_task t = queue[qh++];
+        const uint32_t count = t.end - t.start;
+        const uint32_t* in = ids[t.buf];
+        uint32_t* out = ids[t.buf ^ 1];
+        if (count <= 2) {                                   /* SharedTaskBuilder.cu:396-464, LEAF_THRESHOLD 2 */
+            uint32_t child = t.parent_idx;
+            if (count != 1) { child = write_index; write_index += count; }
+            for (uint32_t i = 0; i < count; i++) {
+                uint32_t prim = in[t.start + i];
+                put_node(&nodes[child + i], boxes[prim], subroots[prim], 2, ORA_TYPE_BOX);
+            }
+            if (count > 1) put_node(&nodes[t.parent_idx], t.p, child, count, ORA_TYPE_BOX);
+            continue;
+        }
+        float cc[2][6], cp[2][6];
+        uint32_t mid;
+        int done = 0;
+        if (!(box_sa(t.c) <= 0.0f)) {                       /* binned SAH (:206-350) */
+            float lx = t.c[3] - t.c[0], ly = t.c[4] - t.c[1], lz = t.c[5] - t.c[2];
+            int axis = 2 * (lz > lx && lz > ly) + 1 * (ly > lx && ly >= lz);
+            const float epsilon = 1.1920929e-7f;
+            float k1 = 8 * (1 - epsilon) / (t.c[3 + axis] - t.c[axis]);
+            float bc[8][6], bp[8][6];
+            uint32_t bn[8];
+            int binof[256];
+            for (int b = 0; b < 8; b++) { box_reset(bc[b]); box_reset(bp[b]); bn[b] = 0; }
+            for (uint32_t i = t.start; i < t.end; i++) {
+                const float* bx = boxes[in[i]];
+                float centre[3] = {(bx[0] + bx[3]) * 0.5f, (bx[1] + bx[4]) * 0.5f, (bx[2] + bx[5]) * 0.5f};
+                int bin = (int)(k1 * (centre[axis] - t.c[axis]));
+                if (bin < 0) bin = 0;                       /* the reference reports an error and aborts the build */
+                if (bin > 7) bin = 7;
+                binof[i] = bin;
+                box_grow(bp[bin], bx);
+                box_grow_pt(bc[bin], centre);
+                bn[bin]++;
+            }
+            /* SelectPlane (:297-350): prefix left->right, sweep right->left, strict <, both sides non-empty */
+            float lc[7][6], lp[7][6];
+            uint32_t ln[7];
+            memcpy(lc[0], bc[0], 24); memcpy(lp[0], bp[0], 24); ln[0] = bn[0];
+            for (int i = 1; i < 7; i++) {
+                memcpy(lc[i], lc[i - 1], 24); memcpy(lp[i], lp[i - 1], 24);
+                box_grow(lc[i], bc[i]); box_grow(lp[i], bp[i]);
+                ln[i] = ln[i - 1] + bn[i];
+            }
+            float rc[6], rp[6];
+            uint32_t rn = bn[7];
+            memcpy(rc, bc[7], 24); memcpy(rp, bp[7], 24);
+            float best = 3.402823466e+38f;
+            int plane = -1;
+            for (int i = 6; i >= 0; i--) {
+                float score = box_sa(lp[i]) * ln[i] + box_sa(rp) * rn;
+                if (score < best && ln[i] && rn) {
+                    best = score; plane = i;
+                    memcpy(cp[0], lp[i], 24); memcpy(cp[1], rp, 24);
+                    memcpy(cc[0], lc[i], 24); memcpy(cc[1], rc, 24);
+                }
+                box_grow(rc, bc[i]); box_grow(rp, bp[i]); rn += bn[i];
+            }
+            if (plane >= 0) {                               /* PartitionIds (:352-380), stable here */
+                uint32_t w = t.start;
+                for (uint32_t i = t.start; i < t.end; i++) if (binof[i] <= plane) out[w++] = in[i];
+                mid = w;
+                for (uint32_t i = t.start; i < t.end; i++) if (binof[i] > plane) out[w++] = in[i];
+                done = 1;
+            }   /* else: "failed to find valid partition" in the reference; falls through to the median split */
+        }
+        if (!done) {                                        /* object split at the midpoint (:465-510) */
+            mid = t.start + (count >> 1);
+            box_reset(cc[0]); box_reset(cc[1]); box_reset(cp[0]); box_reset(cp[1]);
+            for (uint32_t i = t.start; i < t.end; i++) {
+                const float* bx = boxes[in[i]];
+                float centre[3] = {(bx[3] + bx[0]) * 0.5f, (bx[4] + bx[1]) * 0.5f, (bx[5] + bx[2]) * 0.5f};
+                int side = i >= mid;
+                box_grow(cp[side], bx);
+                box_grow_pt(cc[side], centre);
+                out[i] = in[i];
+            }
+        }
+        uint32_t child_index = write_index;                 /* (:544-606) */
+        write_index += 2;
+        put_node(&nodes[t.parent_idx], t.p, child_index, 2, ORA_TYPE_BOX);
+        top_task l, r;
+        memcpy(l.c, cc[0], 24); memcpy(l.p, cp[0], 24);
+        l.start = t.start; l.end = mid; l.parent_idx = child_index; l.buf = t.buf ^ 1;
+        memcpy(r.c, cc[1], 24); memcpy(r.p, cp[1], 24);
+        r.start = mid; r.end = t.end; r.parent_idx = child_index + 1; r.buf = t.buf ^ 1;
+        queue[qt++] = l;
+        queue[qt++] = r;
+    }
+    free(queue);
+    return K;
+}
+
 /* ------------------------------------------------------------------ Utilities.cpp:8-44
  * (recursion restated with an explicit stack so deep trees cannot overflow the C stack) */
 void ora_count_nodes(const ora_node* nodes, uint32_t root, uint32_t count, int32_t out[3])

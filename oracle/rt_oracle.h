@@ -103,6 +103,15 @@ void ora_generate_aabbs(ora_node* nodes, const uint32_t* leaf_indices, const uin
 void ora_build(const ora_triangle* tris, uint32_t n, ora_node* nodes, ora_triangle_pair* leaves,
                uint32_t* codes_sorted, uint32_t* indices_sorted, int32_t* aabb_ordered);
 
+/* Hybrid top tree: ExtractDepth (BottomUpBuilder.cu:314-371) + SharedTaskBuild as launched at
+ * BuildWrapper.cu:350-361, restated DETERMINISTICALLY (the reference emits sub-roots and allocates nodes in
+ * atomic-arrival order): sub-roots in ascending thread id; tasks processed first-in
+ * first-out; node slots allocated in that order; ids partitioned stably.  nodes must hold 2L + 2*256 + 8 slots and
+ * already contain the LBVH of L leaves; scene box as ordered ints.  Writes the top tree at slots >= 2L (top root
+ * descriptor at 2L, trace root = (2L+1, 2), main.cu:222-223).  Returns the number of sub-roots (<= 256).
+ * subroots_out (may be NULL): the sub-root pair indices in emission order. */
+uint32_t ora_build_hybrid_top(ora_node* nodes, uint32_t L, const int32_t aabb_ordered[6], uint32_t* subroots_out);
+
 /* Utilities.cpp:8-44 : out[3] = {numNodes, numLeafNodes, numTreeNodes} */
 void ora_count_nodes(const ora_node* nodes, uint32_t root, uint32_t count, int32_t out[3]);
 /* Utilities.cpp:46-83 : returns the number of failing Box slots (reference prints one line each) */

@@ -209,3 +209,22 @@ def test_trace_depth_against_bruteforce(ora, scenes):
     mism = int((exp != img[..., 0]).sum())
     assert mism <= 3, f"{mism} pixels differ between BVH traversal and brute force"
     assert hit.sum() > 200
+
+
+def test_hybrid_top_tree_oracle(ora, scenes):
+    """The oracle's deterministic ExtractDepth + binned-SAH top tree: valid hierarchy from the top root (also by the
+    reference's compiled checker), all leaves reachable, <= 256 distinct sub-roots 8 levels down, and the same depth
+    frame as the plain LBVH (same primitives -> same nearest hit)."""
+    for tris in (scenes.grid_mesh(24, 1), scenes.soup(5000, 3), scenes.flat_mesh(10, 1), scenes.grid_mesh(2, 1)):
+        h, b = ora.build_hybrid(tris), ora.build_bvh(tris)
+        n, root = h["n"], h["root"]
+        assert root == 2 * n + 1 and 1 <= len(h["subroots"]) <= 256 and len(set(h["subroots"])) == len(h["subroots"])
+        assert ora.verify_hierarchy(h["nodes"], root - 1, 1) == 0
+        assert ora.count_nodes(h["nodes"], root - 1, 1)[1] == n
+        if ora.ref_available():
+            assert ora.ref_verify_hierarchy(h["nodes"], root - 1, 1) == ""
+        lo, hi = ora.ordered_to_float(b["aabb"][:3]), ora.ordered_to_float(b["aabb"][3:])
+        cam = scenes.camera_for_box(lo, hi)
+        i1, _ = ora.trace(b["leaves"], b["nodes"], 0, 2, cam, 96, 64)
+        i2, _ = ora.trace(h["leaves"], h["nodes"], root, 2, cam, 96, 64)
+        assert (i1 == i2).all()
