@@ -40,6 +40,9 @@ namespace rt {
 constexpr int kStackLds = 16;    // LDS-resident stack entries per lane (bench scenes peak at 10)
 constexpr int kStackMax = 64;    // reference stack size (Tracer.cu:314)
 constexpr int kTraceWaves = 4;
+#ifndef RT_TRACE_MIN_WAVES
+#define RT_TRACE_MIN_WAVES 7   // waves per SIMD the register allocator must fit (72 VGPRs: no spills; 8 -> 64 VGPRs spills)
+#endif
 constexpr int kRenderDebugBoxCount = 100;  // internal tuning aid (not in the ABI enum): pixel = raw u32 box-test count
 // the wave runs a box step while  stepping * park_den >= parked * park_num  (else one leaf phase);
 // defaults below, RT_TRACE_PARK="num,den" overrides them at run time (tuning knob).
@@ -362,7 +365,7 @@ __device__ __forceinline__ void shade_sample(const TraceParams& p, const rt_came
 }
 
 template <int RENDER>
-__global__ __launch_bounds__(kTraceWaves * 64) void trace_kernel(TraceParams p)
+__global__ __launch_bounds__(kTraceWaves * 64, RT_TRACE_MIN_WAVES) void trace_kernel(TraceParams p)
 {
     __shared__ uint32_t stack_lds[kTraceWaves][kStackLds][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
