@@ -57,6 +57,7 @@ int rt_bu_scratch_layout_get(uint32_t num_triangles, rt_bu_scratch_layout* out)
     if (!out) return RT_ERR_INVALID_ARGUMENT;
     const BuLayout L = bu_layout(num_triangles);
     out->p_aabb = L.p_aabb;
+    out->status = L.status;
     out->morton = L.morton;
     out->sorted_indices = L.sorted_indices;
     out->total = L.total;
@@ -161,8 +162,8 @@ const char* rt_error_string(int code)
 
 const char* rt_version_string(void)
 {
-    return "rt_amd gfx950 | sort: LSD 4x8bit, tile 4096 | lbvh: LDS agglomerative, 1024 leaves/wg, fan 16 | "
-           "trace: wave64 8x8 tiles, LDS stack 24";
+    return "rt_amd gfx950 | sort: LSD 4x8bit, tile 4096 | lbvh: LDS agglomerative, 1024 leaves/wg, fan 16, hybrid SAH top | "
+           "trace: wave64 8x8 tiles, two-phase schedule, LDS stack 16";
 }
 
 }  // extern "C"

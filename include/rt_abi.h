@@ -122,6 +122,8 @@ int rt_run_bottom_up_build(const rt_build_input* input, const rt_arguments* args
  * sorted Morton codes).  Offsets in bytes. */
 typedef struct rt_bu_scratch_layout {
     size_t p_aabb;          /* int32[6] ordered-int scene box (BuildWrapper.cu:288-289, Multiblock.cu:104) */
+    size_t status;          /* uint32[8]: [0] = error flags of the last build, 0 = ok (bit 0: a workgroup found more
+                               than 128 unfinished sub-trees -- impossible for a tree of depth <= 62) */
     size_t morton;          /* uint32[n] sorted Morton codes after the build */
     size_t sorted_indices;  /* uint32[n] original triangle index per sorted position */
     size_t total;

@@ -24,8 +24,10 @@ def gpu_build(tris: np.ndarray):
                nodes=rt.to_host(inp.nodes_out, rt.NODE, slots),
                leaves=rt.to_host(inp.triangles_out, rt.TRIANGLE_PAIR, n) if n else np.zeros(0, rt.TRIANGLE_PAIR),
                aabb=rt.to_host(inp.scratch, np.int32, 6, lay.p_aabb),
+               status=rt.to_host(inp.scratch, np.uint32, 8, lay.status),
                codes=rt.to_host(inp.scratch, np.uint32, n, lay.morton) if n else np.zeros(0, np.uint32),
                indices=rt.to_host(inp.scratch, np.uint32, n, lay.sorted_indices) if n else np.zeros(0, np.uint32))
+    assert out["status"][0] == 0, f"build reported error flags {out['status'][0]:#x}"
     return out
 
 

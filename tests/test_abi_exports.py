@@ -29,7 +29,7 @@ def test_size_queries_without_gpu(rt):
     assert all(s % 256 == 0 for s in sizes) and sizes == sorted(sizes)
     assert sizes[3] >= 16 * (1 << 20)                              # morton + indices + 2 sort temporaries
     lay = rt.scratch_layout(1000)
-    assert lay.p_aabb == 0 and lay.morton % 256 == 0 and lay.sorted_indices >= lay.morton + 4000
+    assert lay.p_aabb == 0 and lay.status == 32 and lay.morton % 256 == 0 and lay.sorted_indices >= lay.morton + 4000
     assert lay.total == rt.BuMemoryRequirements(1000)
     assert rt.RadixSortScratchBytes(1 << 20) >= 2 * 256 * 256 * 4
     assert "gfx950" in rt.version()

@@ -197,3 +197,38 @@ def test_full_size_1m_properties(rt, scenes, ora):
     oi, oc = ora.trace(o["leaves"], o["nodes"], 0, 2, cam, 1920, 1080, render_type=0)
     assert (gc == oc[:2]).all(), f"{gc} vs {oc}"
     assert (gi == oi).all()
+
+
+def test_build_and_trace_capture_in_a_hip_graph(rt, scenes, ora):
+    """The C ABI neither allocates nor synchronises, so a whole frame -- LBVH rebuild + trace -- can be captured in a
+    hipGraph and replayed (changing triangles / camera in place between replays)."""
+    import torch
+    from helpers import assert_nodes_equal
+    tris_a, tris_b = scenes.grid_mesh(30, 1), scenes.grid_mesh(30, 9)
+    n, w, h = tris_a.shape[0], 160, 96
+    inp = rt.BuildInput.allocate(tris_a)
+    cam_d = rt.to_device(scenes.camera_b(30))
+    frame = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+    counters = torch.zeros(4, dtype=torch.int64, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                       # warm-up outside capture (lazy module load, func attributes)
+        rt.RunBottomUpBuild(inp)
+        rt.Trace(inp.triangles_out, inp.nodes_out, frame, (w, h), cam_d, 0, 2, counters=counters)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        rt.RunBottomUpBuild(inp)
+        rt.Trace(inp.triangles_out, inp.nodes_out, frame, (w, h), cam_d, 0, 2, counters=counters)
+    for tris in (tris_b, tris_a):
+        inp.triangles_in.copy_(rt.to_device(tris))
+        counters.zero_()
+        frame.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        o = ora.build_bvh(tris)
+        assert_nodes_equal(rt.to_host(inp.nodes_out, rt.NODE, 2 * (n - 1)), o["nodes"], "graph replay")
+        img, oc = ora.trace(o["leaves"], o["nodes"], 0, 2, scenes.camera_b(30), w, h)
+        assert (frame.cpu().numpy().reshape(h, w, 4) == img).all()
+        assert (counters.cpu().numpy()[:2].astype(np.uint64) == oc[:2]).all()
