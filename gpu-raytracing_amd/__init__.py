@@ -72,7 +72,8 @@ class _Scene(ctypes.Structure):
 
 
 class _ScratchLayout(ctypes.Structure):
-    _fields_ = [("p_aabb", ctypes.c_size_t), ("status", ctypes.c_size_t), ("morton", ctypes.c_size_t),
+    _fields_ = [("p_aabb", ctypes.c_size_t), ("status", ctypes.c_size_t), ("num_leaves", ctypes.c_size_t),
+                ("morton", ctypes.c_size_t),
                 ("sorted_indices", ctypes.c_size_t), ("total", ctypes.c_size_t)]
 
 

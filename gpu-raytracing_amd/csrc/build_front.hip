@@ -6,6 +6,7 @@
 // issues 6 global atomics per triangle on one 24-byte address).
 #include "rt_device.hpp"
 #include "rt_launch.hpp"
+#include "rt_pairing.hpp"
 
 namespace rt {
 
@@ -141,6 +142,105 @@ __global__ __launch_bounds__(256) void morton_kernel(uint32_t* __restrict__ code
     cz = fmaxf(0.0f, fminf(cz, 1.0f));
     codes[gid] = morton3d(cx, cy, cz);
     values[gid] = gid;
+}
+
+// ---------------------------------------------------------------------------------------------
+// --pairs: GenerateMortonCodesPairs (BottomUpBuilder.cu:117-164).  Candidate k = triangles (2k, 2k+1); it yields one
+// leaf (a merged quad, or a lone last triangle) or two.  The reference claims leaf slots with atomicAdd (arrival
+// order); here slot = exclusive prefix sum of the per-candidate leaf counts in input order:
+//   pair_flags_kernel  : merge decision per candidate (1 byte) + leaf count per workgroup
+//   pair_scan_kernel   : one workgroup scans the workgroup counts, publishes the total number of leaves L
+//   morton_pairs_kernel: workgroup scan + offset -> slot; centres, Morton codes, values (MSB = pair flag)
+constexpr uint32_t kPairThreads = 256;
+
+__global__ __launch_bounds__(kPairThreads) void pair_flags_kernel(const float* __restrict__ f, uint32_t n,
+                                                                  uint8_t* __restrict__ flags,
+                                                                  uint32_t* __restrict__ block_sums)
+{
+    __shared__ uint32_t ws[8];
+    const uint32_t k = blockIdx.x * kPairThreads + threadIdx.x, tid = 2 * k;
+    uint32_t valid = 0;
+    if (tid < n) {
+        bool merge = false;
+        if (tid + 1 < n) {
+            float A[9], B[9];
+            load_tri9(f + (size_t)tid * 9, A);
+            load_tri9(f + (size_t)tid * 9 + 9, B);
+            merge = pair_merges(A, B);
+        }
+        flags[k] = merge ? 1 : 0;
+        valid = 1 + ((tid + 1 < n && !merge) ? 1u : 0u);
+    }
+    uint32_t total;
+    block_excl_scan_u32<kPairThreads>(valid, ws, &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void pair_scan_kernel(uint32_t* __restrict__ block_sums, uint32_t nblocks,
+                                                         uint32_t* __restrict__ num_leaves)
+{
+    __shared__ uint32_t ws[20];
+    uint32_t running = 0;
+    for (uint32_t c = 0; c < nblocks; c += 1024) {
+        const uint32_t i = c + threadIdx.x;
+        const uint32_t v = i < nblocks ? block_sums[i] : 0u;
+        uint32_t chunk;
+        const uint32_t ex = block_excl_scan_u32<1024>(v, ws, &chunk);
+        if (i < nblocks) block_sums[i] = running + ex;
+        running += chunk;
+    }
+    if (threadIdx.x == 0) *num_leaves = running;
+}
+
+__global__ __launch_bounds__(kPairThreads) void morton_pairs_kernel(uint32_t* __restrict__ codes,
+                                                                    uint32_t* __restrict__ values,
+                                                                    const float* __restrict__ f,
+                                                                    const int* __restrict__ aabb,
+                                                                    const uint8_t* __restrict__ flags,
+                                                                    const uint32_t* __restrict__ block_offsets,
+                                                                    uint32_t n)
+{
+    __shared__ uint32_t ws[8];
+    const uint32_t k = blockIdx.x * kPairThreads + threadIdx.x, tid = 2 * k;
+    const bool live = tid < n, second_valid = tid + 1 < n;
+    const bool merge = live && flags[k] != 0;
+    const uint32_t valid = live ? 1 + ((second_valid && !merge) ? 1u : 0u) : 0u;
+    uint32_t total;
+    const uint32_t idx = block_offsets[blockIdx.x] + block_excl_scan_u32<kPairThreads>(valid, ws, &total);
+    if (!live) return;
+    float A[9], B[9];
+    load_tri9(f + (size_t)tid * 9, A);
+    load_tri9(f + (size_t)(second_valid ? tid + 1 : tid) * 9, B);
+    const float mn[3] = {ordered_int_to_float(aabb[0]), ordered_int_to_float(aabb[1]), ordered_int_to_float(aabb[2])};
+    const float mx[3] = {ordered_int_to_float(aabb[3]), ordered_int_to_float(aabb[4]), ordered_int_to_float(aabb[5])};
+    float c1[3], c2[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        c1[j] = ((A[j] + A[3 + j]) + A[6 + j]) / 3.0f;           // Triangle::Centre (Common.cuh:240-242)
+        c2[j] = ((B[j] + B[3 + j]) + B[6 + j]) / 3.0f;
+        if (merge) c1[j] = (c1[j] + c2[j]) * 0.5f;
+        c1[j] = fmaxf(0.0f, fminf((c1[j] - mn[j]) / (mx[j] - mn[j]), 1.0f));
+        c2[j] = fmaxf(0.0f, fminf((c2[j] - mn[j]) / (mx[j] - mn[j]), 1.0f));
+    }
+    values[idx] = merge ? (tid | 0x80000000u) : tid;                // MSB marks a pair (BottomUpBuilder.cu:152-153)
+    codes[idx] = morton3d(c1[0], c1[1], c1[2]);
+    if (second_valid && !merge) {
+        values[idx + 1] = tid + 1;
+        codes[idx + 1] = morton3d(c2[0], c2[1], c2[2]);
+    }
+}
+
+hipError_t launch_morton_pairs(uint32_t* codes, uint32_t* values, const rt_triangle* tris, const int* aabb, uint32_t n,
+                               uint8_t* flags, uint32_t* block_sums, uint32_t* num_leaves, hipStream_t st)
+{
+    const uint32_t cand = (n + 1) / 2;
+    const uint32_t blocks = (cand + kPairThreads - 1) / kPairThreads;
+    const float* f = reinterpret_cast<const float*>(tris);
+    if (n == 0) { pair_scan_kernel<<<1, 1024, 0, st>>>(block_sums, 0, num_leaves); return hipGetLastError(); }
+    pair_flags_kernel<<<blocks, kPairThreads, 0, st>>>(f, n, flags, block_sums);
+    pair_scan_kernel<<<1, 1024, 0, st>>>(block_sums, blocks, num_leaves);
+    morton_pairs_kernel<<<blocks, kPairThreads, 0, st>>>(codes, values, f, aabb, flags, block_sums, n);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -56,8 +56,10 @@ __device__ __forceinline__ void put_node(rt_node* n, const float* b, uint32_t ch
     o[1] = make_uint4(__float_as_uint(b[3]), __float_as_uint(b[4]), __float_as_uint(b[5]), (child & kIndexMask) | (type << 29));
 }
 
-__global__ __launch_bounds__(256) void hybrid_top_kernel(rt_node* nodes, const int* aabb_ordered, uint32_t L)
+__global__ __launch_bounds__(256) void hybrid_top_kernel(rt_node* nodes, const int* aabb_ordered, uint32_t L,
+                                                         const uint32_t* n_dev)
 {
+    if (n_dev) L = *n_dev;   // --pairs: the leaf count is a device value
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     TopSmem& S = *reinterpret_cast<TopSmem*>(smem_raw);
     const uint32_t tid = threadIdx.x;
@@ -306,7 +308,7 @@ __global__ void hybrid_empty_kernel(rt_node* nodes)
     reinterpret_cast<uint32_t*>(nodes)[threadIdx.x] = 0;   // slots 0..7
 }
 
-hipError_t launch_hybrid_top(rt_node* nodes, const int* aabb_ordered, uint32_t n, hipStream_t st)
+hipError_t launch_hybrid_top(rt_node* nodes, const int* aabb_ordered, uint32_t n, hipStream_t st, const uint32_t* n_dev)
 {
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
@@ -316,7 +318,7 @@ hipError_t launch_hybrid_top(rt_node* nodes, const int* aabb_ordered, uint32_t n
     });
     if (attr_err != hipSuccess) return attr_err;
     if (n == 0) hybrid_empty_kernel<<<1, 64, 0, st>>>(nodes);
-    else hybrid_top_kernel<<<1, 256, sizeof(TopSmem), st>>>(nodes, aabb_ordered, n);
+    else hybrid_top_kernel<<<1, 256, sizeof(TopSmem), st>>>(nodes, aabb_ordered, n, n_dev);
     return hipGetLastError();
 }
 

@@ -32,6 +32,7 @@
 
 #include "rt_device.hpp"
 #include "rt_launch.hpp"
+#include "rt_pairing.hpp"
 
 namespace rt {
 
@@ -42,7 +43,8 @@ struct LevelArgs {
     const float* tris;           // 9 floats per triangle
     const uint32_t* codes;       // sorted Morton codes
     const uint32_t* sorted_idx;  // original triangle per sorted position
-    uint32_t n;
+    uint32_t n;                  // number of leaves; superseded by *n_dev when that is set (--pairs: L is a device value)
+    const uint32_t* n_dev;
     rt_triangle_pair* leaves;
     rt_node* nodes;
     const uint32_t* prev_cnt;    // upper levels: open-root counts of the previous level's workgroups
@@ -94,12 +96,12 @@ __global__ __launch_bounds__(1024) void lbvh_level_kernel(LevelArgs a)
     uint32_t* pref = smem + C::oWs + 32;  // [0..17) prefix of previous-level counts
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t n = a.n;
+    const uint32_t n = a.n_dev ? *a.n_dev : a.n;
     const uint32_t B0 = blockIdx.x * kLeafCap;  // leaf level only
     uint32_t S;
 
     if (LEAF) {
-        S = min(kLeafCap, n - B0);
+        S = B0 < n ? min(kLeafCap, n - B0) : 0u;   // grids are sized for the largest possible n
     } else {
         if (tid < 64) {
             const uint32_t pb = blockIdx.x * kUpperFan + tid;
@@ -141,23 +143,45 @@ __global__ __launch_bounds__(1024) void lbvh_level_kernel(LevelArgs a)
             // GenerateTriangles (BottomUpBuilder.cu:287-312) fused: gather the triangle, emit the
             // 64-byte leaf in sorted order (ids defined), keep its box in registers.
             const uint32_t i = B0 + s0;
-            const uint32_t src = a.sorted_idx[i] & 0x7FFFFFFFu;
-            // 36 bytes at a 4-byte-aligned address: two 16-byte loads + one dword (3 instructions instead of 9;
-            // global loads need only dword alignment on gfx950)
-            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-            const float* t = a.tris + (size_t)src * 9;
-            const f4u ta = *reinterpret_cast<const f4u*>(t), tb = *reinterpret_cast<const f4u*>(t + 4);
-            const float v[9] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w, t[8]};
+            const uint32_t sv = a.sorted_idx[i];
+            const uint32_t src = sv & 0x7FFFFFFFu;
+            float v[9];
+            load_tri9(a.tris + (size_t)src * 9, v);   // 36 bytes at a 4-byte-aligned address: 2 x 16-byte loads + 1 dword
             uint4* out = reinterpret_cast<uint4*>(a.leaves + i);
-            out[0] = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), src);
-            out[1] = make_uint4(__float_as_uint(v[3]), __float_as_uint(v[4]), __float_as_uint(v[5]), 0u);
-            out[2] = make_uint4(__float_as_uint(v[6]), __float_as_uint(v[7]), __float_as_uint(v[8]), 0u);
-            out[3] = make_uint4(__float_as_uint(v[6]), __float_as_uint(v[7]), __float_as_uint(v[8]), 0u);
-            // GenerateAABBs leaf box (BottomUpBuilder.cu:259-263)
+            float v3[3] = {v[6], v[7], v[8]};
+            if (sv >> 31) {
+                // a quad leaf (--pairs): CreateTrianglePair (Pairing.cuh:60-77): A rotated so the shared edge is
+                // (v1, v2), v3 = B's vertex off that edge; ids = (src, src+1); rotations = (rot_a, rot_b)
+                float B[9];
+                load_tri9(a.tris + (size_t)src * 9 + 9, B);
+                int ra = 0, rb = 0;
+                can_form_pair(v, B, ra, rb);
+                float r[9];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    r[k] = ra == 1 ? v[6 + k] : (ra == 2 ? v[3 + k] : v[k]);
+                    r[3 + k] = ra == 1 ? v[k] : (ra == 2 ? v[6 + k] : v[3 + k]);
+                    r[6 + k] = ra == 1 ? v[3 + k] : (ra == 2 ? v[k] : v[6 + k]);
+                    v3[k] = rb == 2 ? B[k] : (rb == 1 ? B[3 + k] : B[6 + k]);
+                }
+#pragma unroll
+                for (int k = 0; k < 9; k++) v[k] = r[k];
+                out[0] = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), src);
+                out[1] = make_uint4(__float_as_uint(v[3]), __float_as_uint(v[4]), __float_as_uint(v[5]), src + 1);
+                out[2] = make_uint4(__float_as_uint(v[6]), __float_as_uint(v[7]), __float_as_uint(v[8]), (uint32_t)ra | ((uint32_t)rb << 16));
+                out[3] = make_uint4(__float_as_uint(v3[0]), __float_as_uint(v3[1]), __float_as_uint(v3[2]), 0u);
+            } else {
+                // GenerateTriangles (BottomUpBuilder.cu:287-312) fused: the 64-byte leaf in sorted order (ids defined)
+                out[0] = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), src);
+                out[1] = make_uint4(__float_as_uint(v[3]), __float_as_uint(v[4]), __float_as_uint(v[5]), 0u);
+                out[2] = make_uint4(__float_as_uint(v[6]), __float_as_uint(v[7]), __float_as_uint(v[8]), 0u);
+                out[3] = make_uint4(__float_as_uint(v[6]), __float_as_uint(v[7]), __float_as_uint(v[8]), 0u);
+            }
+            // GenerateAABBs leaf box (BottomUpBuilder.cu:259-267; v3 only widens it for a quad, it equals v2 otherwise)
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                bx[k] = fminf(fminf(v[k], v[3 + k]), v[6 + k]);
-                bx[3 + k] = fmaxf(fmaxf(v[k], v[3 + k]), v[6 + k]);
+                bx[k] = fminf(fminf(fminf(v[k], v[3 + k]), v[6 + k]), v3[k]);
+                bx[3 + k] = fmaxf(fmaxf(fmaxf(v[k], v[3 + k]), v[6 + k]), v3[k]);
             }
             desc = (i & kIndexMask) | ((uint32_t)RT_CHILD_TRI << 29);
             cc = 0;
@@ -288,19 +312,20 @@ __global__ __launch_bounds__(1024) void lbvh_level_kernel(LevelArgs a)
 }
 
 // n < 2: n == 1 -> slot 0 describes the single leaf, slot 1 is type None; n == 0 -> both None.
-__global__ void lbvh_tiny_kernel(const rt_triangle_pair* leaves, rt_node* nodes, uint32_t n)
+__global__ void lbvh_tiny_kernel(const rt_triangle_pair* leaves, rt_node* nodes, uint32_t n, const uint32_t* n_dev)
 {
-    if (threadIdx.x != 0) return;
+    if (n_dev) n = *n_dev;
+    if (threadIdx.x != 0 || n >= 2) return;
     uint32_t* nw = reinterpret_cast<uint32_t*>(nodes);
     for (int k = 0; k < 16; k++) nw[k] = 0;
     if (n == 1) {
         const rt_triangle_pair t = leaves[0];
-        nodes[0].min.x = fminf(fminf(t.v0.x, t.v1.x), t.v2.x);
-        nodes[0].min.y = fminf(fminf(t.v0.y, t.v1.y), t.v2.y);
-        nodes[0].min.z = fminf(fminf(t.v0.z, t.v1.z), t.v2.z);
-        nodes[0].max.x = fmaxf(fmaxf(t.v0.x, t.v1.x), t.v2.x);
-        nodes[0].max.y = fmaxf(fmaxf(t.v0.y, t.v1.y), t.v2.y);
-        nodes[0].max.z = fmaxf(fmaxf(t.v0.z, t.v1.z), t.v2.z);
+        nodes[0].min.x = fminf(fminf(fminf(t.v0.x, t.v1.x), t.v2.x), t.v3.x);
+        nodes[0].min.y = fminf(fminf(fminf(t.v0.y, t.v1.y), t.v2.y), t.v3.y);
+        nodes[0].min.z = fminf(fminf(fminf(t.v0.z, t.v1.z), t.v2.z), t.v3.z);
+        nodes[0].max.x = fmaxf(fmaxf(fmaxf(t.v0.x, t.v1.x), t.v2.x), t.v3.x);
+        nodes[0].max.y = fmaxf(fmaxf(fmaxf(t.v0.y, t.v1.y), t.v2.y), t.v3.y);
+        nodes[0].max.z = fmaxf(fmaxf(fmaxf(t.v0.z, t.v1.z), t.v2.z), t.v3.z);
         nodes[0].w12 = 1u << 29;
         nodes[0].w28 = 0u | ((uint32_t)RT_CHILD_TRI << 29);
     }
@@ -329,7 +354,7 @@ LevelPlan lbvh_level_plan(uint32_t n)
 
 hipError_t launch_lbvh_levels(const rt_triangle* tris, const uint32_t* codes, const uint32_t* sorted_indices,
                               uint32_t n, rt_triangle_pair* leaves, rt_node* nodes, void* level_scratch,
-                              uint32_t* status, hipStream_t st)
+                              uint32_t* status, hipStream_t st, const uint32_t* n_dev)
 {
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
@@ -350,6 +375,7 @@ hipError_t launch_lbvh_levels(const rt_triangle* tris, const uint32_t* codes, co
         a.codes = codes;
         a.sorted_idx = sorted_indices;
         a.n = n;
+        a.n_dev = n_dev;
         a.leaves = leaves;
         a.nodes = nodes;
         a.status = status;
@@ -365,7 +391,7 @@ hipError_t launch_lbvh_levels(const rt_triangle* tris, const uint32_t* codes, co
                 lbvh_level_kernel<false><<<p.blocks[k], 1024, LevelCfg<false>::kBytes, st>>>(a);
         }
     }
-    if (n < 2) lbvh_tiny_kernel<<<1, 64, 0, st>>>(leaves, nodes, n);
+    if (n < 2 || n_dev) lbvh_tiny_kernel<<<1, 64, 0, st>>>(leaves, nodes, n, n_dev);
     return hipGetLastError();
 }
 

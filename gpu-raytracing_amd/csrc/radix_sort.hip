@@ -30,8 +30,9 @@ __device__ __forceinline__ uint64_t match_digit8(uint32_t d, bool valid)
 
 __global__ __launch_bounds__(256) void sort_upsweep_kernel(const uint32_t* __restrict__ keys, uint32_t n,
                                                            uint32_t shift, uint32_t num_tiles,
-                                                           uint32_t* __restrict__ hist)
+                                                           uint32_t* __restrict__ hist, const uint32_t* n_dev)
 {
+    if (n_dev) n = *n_dev;   // device-side count (--pairs): tiles past it see no valid key and publish zeros
     __shared__ uint32_t h[kRadix];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -84,8 +85,10 @@ __global__ __launch_bounds__(256) void sort_downsweep_kernel(const uint32_t* __r
                                                              uint32_t* __restrict__ vals_out, uint32_t n,
                                                              uint32_t shift, uint32_t num_tiles,
                                                              const uint32_t* __restrict__ offs,
-                                                             const uint32_t* __restrict__ totals)
+                                                             const uint32_t* __restrict__ totals,
+                                                             const uint32_t* n_dev)
 {
+    if (n_dev) n = *n_dev;
     // wave_hist[w][d]: first the running count of digit d inside wave w's chunk, later the position inside the
     // tile (sorted by digit) of wave w's first key with digit d.
     __shared__ uint32_t wave_hist[4][kRadix];
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256) void sort_downsweep_kernel(const uint32_t* __r
     }
     __syncthreads();
     const uint32_t tbase = tile * kSortTile;
-    const uint32_t nvalid = min(kSortTile, n - tbase);
+    const uint32_t nvalid = tbase < n ? min(kSortTile, n - tbase) : 0u;
 #pragma unroll
     for (int i = 0; i < (int)kSortItems; i++) {
         const uint32_t j = i * kSortThreads + threadIdx.x;
@@ -177,7 +180,7 @@ SortScratch sort_scratch_layout(uint32_t n)
 }
 
 hipError_t launch_radix_sort(uint32_t* keys, uint32_t* vals, uint32_t* tmp_keys, uint32_t* tmp_vals, uint32_t n,
-                             void* sort_scratch, hipStream_t st)
+                             void* sort_scratch, hipStream_t st, const uint32_t* n_dev)
 {
     if (n == 0) return hipSuccess;
     const SortScratch L = sort_scratch_layout(n);
@@ -191,9 +194,9 @@ hipError_t launch_radix_sort(uint32_t* keys, uint32_t* vals, uint32_t* tmp_keys,
     for (uint32_t pass = 0; pass < kSortPasses; pass++) {
         const uint32_t shift = pass * kRadixBits;
         uint32_t* dt = digit_total + pass * kRadix;
-        sort_upsweep_kernel<<<tiles, kSortThreads, 0, st>>>(sk, n, shift, tiles, hist);
+        sort_upsweep_kernel<<<tiles, kSortThreads, 0, st>>>(sk, n, shift, tiles, hist, n_dev);
         sort_scan_kernel<<<kRadix, 256, 0, st>>>(hist, tiles, offs, dt);
-        sort_downsweep_kernel<<<tiles, kSortThreads, 0, st>>>(sk, sv, dk, dv, n, shift, tiles, offs, dt);
+        sort_downsweep_kernel<<<tiles, kSortThreads, 0, st>>>(sk, sv, dk, dv, n, shift, tiles, offs, dt, n_dev);
         uint32_t* x;
         x = sk; sk = dk; dk = x;
         x = sv; sv = dv; dv = x;

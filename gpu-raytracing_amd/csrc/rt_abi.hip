@@ -24,6 +24,8 @@ BuLayout bu_layout(uint32_t n)
     L.sort = off;           off = align_up(off + sort_scratch_layout(n).total, 256);
     L.levels = off;         off = align_up(off + lbvh_level_plan(n).total, 256);
     L.hybrid = off;         off = align_up(off + 64 * 1024, 256);
+    L.pair_flags = off;     off = align_up(off + (nn + 1) / 2, 256);
+    L.pair_sums = off;      off = align_up(off + ((nn + 1) / 2 / 256 + 2) * 4, 256);
     L.total = off;
     return L;
 }
@@ -32,9 +34,9 @@ static inline int hip_rc(hipError_t e) { return e == hipSuccess ? RT_OK : RT_ERR
 
 // one launch for the build's tiny initialisations: status words = 0 and the ordered-int "empty" scene box
 // (BuildWrapper.cu:288-303 does these with 6 memset / memcpy calls)
-__global__ void build_init_kernel(uint32_t* status, int* aabb)
+__global__ void build_init_kernel(uint32_t* status, int* aabb, uint32_t n)
 {
-    if (threadIdx.x < 8) status[threadIdx.x] = 0;
+    if (threadIdx.x < 8) status[threadIdx.x] = threadIdx.x == 1 ? n : 0;   // [1] = number of leaves (pairs: overwritten)
     if (threadIdx.x < 6) aabb[threadIdx.x] = threadIdx.x < 3 ? 0x7f7fffff : (int)0x80800000;
 }
 
@@ -58,6 +60,7 @@ int rt_bu_scratch_layout_get(uint32_t num_triangles, rt_bu_scratch_layout* out)
     const BuLayout L = bu_layout(num_triangles);
     out->p_aabb = L.p_aabb;
     out->status = L.status;
+    out->num_leaves = L.status + 4;
     out->morton = L.morton;
     out->sorted_indices = L.sorted_indices;
     out->total = L.total;
@@ -96,7 +99,8 @@ int rt_run_bottom_up_build(const rt_build_input* input, const rt_arguments* args
     const uint32_t n = input->num_triangles;
     if (n && (!input->triangles_in || !input->triangles_out)) return RT_ERR_INVALID_ARGUMENT;
     if (n > (1u << 28)) return RT_ERR_TOO_LARGE;  // 2(n-1) slots must fit the 29-bit child field
-    if (args && (args->enable_pairs || args->enable_splits)) return RT_ERR_UNSUPPORTED;
+    if (args && args->enable_splits) return RT_ERR_UNSUPPORTED;  // SURVEY 8(f) rank 3 (spatial-split pre-pass of the SAH path)
+    const bool pairs = args && args->enable_pairs;
     if ((reinterpret_cast<uintptr_t>(input->scratch) & 255u) || (reinterpret_cast<uintptr_t>(input->triangles_in) & 15u) ||
         (reinterpret_cast<uintptr_t>(input->triangles_out) & 63u) || (reinterpret_cast<uintptr_t>(input->nodes_out) & 63u))
         return RT_ERR_INVALID_ARGUMENT;
@@ -111,15 +115,26 @@ int rt_run_bottom_up_build(const rt_build_input* input, const rt_arguments* args
     uint32_t* tmpk = reinterpret_cast<uint32_t*>(s + L.tmp_keys);
     uint32_t* tmpv = reinterpret_cast<uint32_t*>(s + L.tmp_vals);
 
-    build_init_kernel<<<1, 64, 0, st>>>(status, p_aabb);
+    build_init_kernel<<<1, 64, 0, st>>>(status, p_aabb, n);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = launch_scene_aabb(input->triangles_in, n, p_aabb, st);
-    if (e == hipSuccess) e = launch_morton(morton, sorted, input->triangles_in, p_aabb, n, st);
-    if (e == hipSuccess) e = launch_radix_sort(morton, sorted, tmpk, tmpv, n, s + L.sort, st);
+    // with --pairs the number of leaves L <= n is only known on the device (status[1]); the reference copies it
+    // back to the host (BuildWrapper.cu:317-321, a sync) -- here the downstream kernels read it from memory and the
+    // grids are sized for n
+    uint32_t* num_leaves = status + 1;
+    const uint32_t* n_dev = pairs ? num_leaves : nullptr;
+    if (e == hipSuccess) {
+        if (pairs)
+            e = launch_morton_pairs(morton, sorted, input->triangles_in, p_aabb, n, reinterpret_cast<uint8_t*>(s + L.pair_flags),
+                                    reinterpret_cast<uint32_t*>(s + L.pair_sums), num_leaves, st);
+        else
+            e = launch_morton(morton, sorted, input->triangles_in, p_aabb, n, st);
+    }
+    if (e == hipSuccess) e = launch_radix_sort(morton, sorted, tmpk, tmpv, n, s + L.sort, st, n_dev);
     if (e == hipSuccess)
         e = launch_lbvh_levels(input->triangles_in, morton, sorted, n, input->triangles_out, input->nodes_out,
-                               s + L.levels, status, st);
-    if (e == hipSuccess && hybrid) e = launch_hybrid_top(input->nodes_out, p_aabb, n, st);   // BuildWrapper.cu:350-361
+                               s + L.levels, status, st, n_dev);
+    if (e == hipSuccess && hybrid) e = launch_hybrid_top(input->nodes_out, p_aabb, n, st, n_dev);   // BuildWrapper.cu:350-361
     return hip_rc(e);
 }
 
@@ -152,7 +167,7 @@ const char* rt_error_string(int code)
     switch (code) {
     case RT_OK: return "ok";
     case RT_ERR_INVALID_ARGUMENT: return "invalid argument";
-    case RT_ERR_UNSUPPORTED: return "unsupported option (pairs / splits / SAH / textured render type)";
+    case RT_ERR_UNSUPPORTED: return "unsupported option (splits / SAH builder / textured render type)";
     case RT_ERR_TOO_LARGE: return "too many triangles for the 29-bit node index";
     default: break;
     }

@@ -47,7 +47,7 @@ LevelPlan lbvh_level_plan(uint32_t n);
 // ---- whole-build scratch layout
 struct BuLayout {
     size_t p_aabb;          // int32[6]
-    size_t status;          // uint32[8]: [0] error flags
+    size_t status;          // uint32[8]: [0] error flags, [1] number of leaves L of the last build
     size_t morton;          // uint32[n]
     size_t sorted_indices;  // uint32[n]
     size_t tmp_keys;        // uint32[n]
@@ -55,6 +55,8 @@ struct BuLayout {
     size_t sort;            // SortScratch
     size_t levels;          // LevelPlan
     size_t hybrid;          // hybrid top-tree work area
+    size_t pair_flags;      // uint8[(n+1)/2] merge decision per candidate (--pairs)
+    size_t pair_sums;       // uint32[ceil((n+1)/2 / 256)] leaf counts / offsets per workgroup (--pairs)
     size_t total;
 };
 BuLayout bu_layout(uint32_t n);
@@ -64,13 +66,17 @@ hipError_t launch_reset_aabb(int* aabb, hipStream_t st);
 hipError_t launch_scene_aabb(const rt_triangle* tris, uint32_t n, int* aabb, hipStream_t st);
 hipError_t launch_morton(uint32_t* codes, uint32_t* values, const rt_triangle* tris, const int* aabb, uint32_t n,
                          hipStream_t st);
+hipError_t launch_morton_pairs(uint32_t* codes, uint32_t* values, const rt_triangle* tris, const int* aabb, uint32_t n,
+                               uint8_t* flags, uint32_t* block_sums, uint32_t* num_leaves, hipStream_t st);
+// n_dev (may be null): device word holding the real element count (<= n); n then only sizes the grids
 hipError_t launch_radix_sort(uint32_t* keys, uint32_t* vals, uint32_t* tmp_keys, uint32_t* tmp_vals, uint32_t n,
-                             void* sort_scratch, hipStream_t st);
+                             void* sort_scratch, hipStream_t st, const uint32_t* n_dev = nullptr);
 hipError_t launch_lbvh_levels(const rt_triangle* tris, const uint32_t* codes, const uint32_t* sorted_indices,
                               uint32_t n, rt_triangle_pair* leaves, rt_node* nodes, void* level_scratch,
-                              uint32_t* status, hipStream_t st);
+                              uint32_t* status, hipStream_t st, const uint32_t* n_dev = nullptr);
 
-hipError_t launch_hybrid_top(rt_node* nodes, const int* aabb_ordered, uint32_t n, hipStream_t st);
+hipError_t launch_hybrid_top(rt_node* nodes, const int* aabb_ordered, uint32_t n, hipStream_t st,
+                             const uint32_t* n_dev = nullptr);
 
 struct TraceLaunch {
     rt_accel as;

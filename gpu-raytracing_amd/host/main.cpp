@@ -60,7 +60,6 @@ int main(int argc, char** argv)
     Scene scene = LoadOBJFromFile(g_filename);
     const unsigned n = (unsigned)scene.triangles.size();
     const bool hybrid = args.build_type == kHybrid;
-    const unsigned root_index = hybrid ? n * 2 + 1 : 0;   // main.cu:222
     const unsigned root_count = 2;                        // main.cu:223 (bottom-up / hybrid)
 
     MemoryBuffer<Camera> camera(1);
@@ -91,6 +90,14 @@ int main(int argc, char** argv)
     float build_ms = 0;
     check(hipEventElapsedTime(&build_ms, e0, e1));
     printf("RunBottomUpBuild time elapsed: %fms\n", build_ms);
+    // number of leaves L: n, unless --pairs merged triangles.  The reference roots a hybrid tree at 2n+1 even then
+    // (main.cu:222); the top tree is written at 2L, so the root is 2L+1.
+    rt_bu_scratch_layout lay;
+    rt_bu_scratch_layout_get(n, &lay);
+    unsigned num_leaves = n;
+    check(hipMemcpy(&num_leaves, static_cast<char*>(in.scratch) + lay.num_leaves, 4, hipMemcpyDeviceToHost));
+    const unsigned root_index = hybrid ? (num_leaves * 2 > 2 ? num_leaves * 2 : 2) + 1 : 0;
+    if (args.enable_pairs) printf("  leaves after pairing: %u of %u triangles\n", num_leaves, n);
 
     std::vector<Node> nodes((size_t)(n ? n : 1) * 4);
     check(hipMemcpy(nodes.data(), in.nodes_out, sizeof(Node) * nodes.size(), hipMemcpyDeviceToHost));

@@ -100,7 +100,7 @@ typedef struct rt_scene {
 enum {
     RT_OK = 0,
     RT_ERR_INVALID_ARGUMENT = -1,
-    RT_ERR_UNSUPPORTED = -2,       /* pairs / splits / SAH builder / textured render types: SURVEY 8(f) "next" rows */
+    RT_ERR_UNSUPPORTED = -2,       /* splits / SAH builder / textured render types: SURVEY 8(f) "next" rows */
     RT_ERR_TOO_LARGE = -3,         /* n exceeds the 29-bit child index of Node (Common.cuh:152-159) */
     RT_ERR_HIP_BASE = -1000        /* -(hipError_t) + RT_ERR_HIP_BASE */
 };
@@ -115,7 +115,10 @@ size_t rt_nodes_bytes(uint32_t num_triangles);
 /* replaces RunBottomUpBuild (BuildWrapper.cu:253-362).  hybrid != 0 additionally builds the SAH top
  * tree above the 8-level-deep LBVH sub-roots (ExtractDepth + SharedTaskBuild, BuildWrapper.cu:350-361);
  * trace root is then (2n+1, 2) instead of (0, 2) (main.cu:222-223).  The top tree is built deterministically
- * (the reference's numbering depends on atomic arrival order); it occupies slots [2n, 2n + 2*256 + 2). */
+ * (the reference's numbering depends on atomic arrival order); it occupies slots [2L, 2L + 2*256 + 2).
+ * args->enable_pairs (Pairing.cuh, GenerateMortonCodesPairs): triangles 2k, 2k+1 sharing an edge become one quad
+ * leaf; leaf slots are assigned by a prefix sum in input order (the reference uses atomicAdd arrival order), the
+ * leaf count L lands in scratch (rt_bu_scratch_layout.num_leaves); hybrid + pairs roots at (2L+1, 2). */
 int rt_run_bottom_up_build(const rt_build_input* input, const rt_arguments* args, int hybrid, void* stream);
 
 /* Where the build's intermediates live inside `scratch` (for parity tests and callers that want the
@@ -124,6 +127,7 @@ typedef struct rt_bu_scratch_layout {
     size_t p_aabb;          /* int32[6] ordered-int scene box (BuildWrapper.cu:288-289, Multiblock.cu:104) */
     size_t status;          /* uint32[8]: [0] = error flags of the last build, 0 = ok (bit 0: a workgroup found more
                                than 128 unfinished sub-trees -- impossible for a tree of depth <= 62) */
+    size_t num_leaves;      /* uint32: number of leaves L of the last build (= n unless args.enable_pairs merged triangles) */
     size_t morton;          /* uint32[n] sorted Morton codes after the build */
     size_t sorted_indices;  /* uint32[n] original triangle index per sorted position */
     size_t total;

@@ -41,6 +41,8 @@ def lib() -> ctypes.CDLL:
         L.ora_morton_codes.argtypes = [vp, u32, vp, vp, vp]
         L.ora_radix_sort.argtypes = [vp, vp, vp, vp, u32]
         L.ora_build.argtypes = [vp, u32, vp, vp, vp, vp, vp]
+        L.ora_build_pairs.argtypes = [vp, u32, vp, vp, vp, vp, vp]
+        L.ora_build_pairs.restype = u32
         L.ora_build_hybrid_top.argtypes = [vp, u32, vp, vp]
         L.ora_build_hybrid_top.restype = u32
         L.ora_count_nodes.argtypes = [vp, u32, u32, vp]
@@ -98,6 +100,18 @@ def build_bvh(tris: np.ndarray) -> dict:
     aabb = np.zeros(6, np.int32)
     lib().ora_build(_p(t), n, _p(nodes), _p(leaves), _p(codes), _p(idx), _p(aabb))
     return dict(nodes=nodes, leaves=leaves[:n], codes=codes[:n], indices=idx[:n], aabb=aabb, n=n)
+
+
+def build_pairs(tris: np.ndarray) -> dict:
+    """RunBottomUpBuild with enable_pairs: shared-edge triangle pairs become quad leaves (deterministic slots)."""
+    t = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1, 9)
+    n = t.shape[0]
+    nodes = np.zeros(2 * max(n - 1, 1), dtype=NODE)
+    leaves = np.zeros(max(n, 1), dtype=TRIANGLE_PAIR)
+    codes, idx = np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.uint32)
+    aabb = np.zeros(6, np.int32)
+    L = int(lib().ora_build_pairs(_p(t), n, _p(nodes), _p(leaves), _p(codes), _p(idx), _p(aabb)))
+    return dict(nodes=nodes[:2 * max(L - 1, 1)], leaves=leaves[:L], codes=codes[:L], indices=idx[:L], aabb=aabb, n=n, L=L)
 
 
 def build_hybrid(tris: np.ndarray) -> dict:

@@ -342,6 +342,139 @@ void ora_build(const ora_triangle* tris, uint32_t n, ora_node* nodes, ora_triang
     free(codes); free(vals); free(t1); free(t2);
 }
 
+/* ================================================================== --pairs (Pairing.cuh)
+ * FindSharedEdge (:26-33): does triangle t contain the directed edge a->b?  returns the rotation of t, or -1 */
+static inline int vequal(ora_f3 a, ora_f3 b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+static int find_shared_edge(ora_f3 a, ora_f3 b, const ora_triangle* t)
+{
+    if (vequal(a, t->v0) && vequal(b, t->v1)) return 0;
+    if (vequal(a, t->v1) && vequal(b, t->v2)) return 2;
+    if (vequal(a, t->v2) && vequal(b, t->v0)) return 1;
+    return -1;
+}
+static inline ora_f3 tri_vertex(const ora_triangle* t, int i) { return i == 0 ? t->v0 : i == 1 ? t->v1 : t->v2; }
+/* CanFormTrianglePair (:42-58) */
+static int can_form_pair(const ora_triangle* a, const ora_triangle* b, int* rot_a, int* rot_b)
+{
+    int t0 = 3, t1 = -1;
+    for (int u = 2, v = 0; v < 3; u = v, v++) {
+        t1 = find_shared_edge(tri_vertex(a, v), tri_vertex(a, u), b);
+        t0--;
+        if (t1 != -1) break;
+    }
+    if (t1 == -1) return 0;
+    *rot_a = t0;
+    *rot_b = t1;
+    return 1;
+}
+static inline void tri_box(const ora_triangle* t, float* b)   /* AABB(Triangle), Common.cuh:265-269 */
+{
+    ora_f3 lo = min3(min3(t->v0, t->v1), t->v2), hi = max3(max3(t->v0, t->v1), t->v2);
+    b[0] = lo.x; b[1] = lo.y; b[2] = lo.z; b[3] = hi.x; b[4] = hi.y; b[5] = hi.z;
+}
+static inline float sa6(const float* b)
+{
+    float lx = b[3] - b[0], ly = b[4] - b[1], lz = b[5] - b[2];
+    return 2.0f * (lx * ly + lx * lz + ly * lz);
+}
+/* merge decision of candidate (2k, 2k+1) (BottomUpBuilder.cu:127-138, ShouldFormTrianglePair Pairing.cuh:35-39) */
+static int pair_merges(const ora_triangle* tris, uint32_t n, uint32_t tid)
+{
+    if (tid + 1 >= n) return 0;
+    const ora_triangle *a = &tris[tid], *b = &tris[tid + 1];
+    int ra, rb;
+    if (!can_form_pair(a, b, &ra, &rb)) return 0;
+    float ab[6], bb[6], cb[6];
+    tri_box(a, ab);
+    tri_box(b, bb);
+    for (int k = 0; k < 3; k++) { cb[k] = fminf(ab[k], bb[k]); cb[3 + k] = fmaxf(ab[3 + k], bb[3 + k]); }
+    return sa6(cb) * 0.5f < sa6(ab) + sa6(bb);
+}
+
+uint32_t ora_build_pairs(const ora_triangle* tris, uint32_t n, ora_node* nodes, ora_triangle_pair* leaves,
+                         uint32_t* codes_sorted, uint32_t* indices_sorted, int32_t* aabb_ordered)
+{
+    uint32_t slots = 2 * (n > 1 ? n - 1 : 1);
+    memset(nodes, 0, (size_t)slots * sizeof(ora_node));
+    int32_t aabb[6];
+    ora_scene_aabb(tris, n, aabb);
+    if (aabb_ordered) memcpy(aabb_ordered, aabb, sizeof aabb);
+    if (n == 0) return 0;
+    ora_f3 smin = f3(ora_ordered_int_to_float(aabb[0]), ora_ordered_int_to_float(aabb[1]), ora_ordered_int_to_float(aabb[2]));
+    ora_f3 smax = f3(ora_ordered_int_to_float(aabb[3]), ora_ordered_int_to_float(aabb[4]), ora_ordered_int_to_float(aabb[5]));
+    ora_f3 ext = sub3(smax, smin);
+
+    uint32_t* codes = (uint32_t*)malloc((size_t)n * 4);
+    uint32_t* vals = (uint32_t*)malloc((size_t)n * 4);
+    uint32_t* t1 = (uint32_t*)calloc((size_t)n, 4);
+    uint32_t* t2 = (uint32_t*)calloc((size_t)n, 4);
+    /* GenerateMortonCodesPairs with slots assigned in input order */
+    uint32_t L = 0;
+    for (uint32_t tid = 0; tid < n; tid += 2) {
+        const int second_valid = tid + 1 < n;
+        const int merge = pair_merges(tris, n, tid);
+        const ora_triangle *a = &tris[tid], *b = second_valid ? &tris[tid + 1] : &tris[tid];
+        ora_f3 centre = add3(add3(a->v0, a->v1), a->v2);
+        centre = f3(centre.x / 3.0f, centre.y / 3.0f, centre.z / 3.0f);
+        ora_f3 centre2 = add3(add3(b->v0, b->v1), b->v2);
+        centre2 = f3(centre2.x / 3.0f, centre2.y / 3.0f, centre2.z / 3.0f);
+        if (merge) centre = scale3(add3(centre, centre2), 0.5f);
+        ora_f3 c = div3(sub3(centre, smin), ext);
+        c = f3(clampf(c.x, 0.0f, 1.0f), clampf(c.y, 0.0f, 1.0f), clampf(c.z, 0.0f, 1.0f));
+        vals[L] = merge ? (tid | 0x80000000u) : tid;
+        codes[L] = morton3d(c.x, c.y, c.z);
+        L++;
+        if (second_valid && !merge) {
+            ora_f3 c2 = div3(sub3(centre2, smin), ext);
+            c2 = f3(clampf(c2.x, 0.0f, 1.0f), clampf(c2.y, 0.0f, 1.0f), clampf(c2.z, 0.0f, 1.0f));
+            vals[L] = tid + 1;
+            codes[L] = morton3d(c2.x, c2.y, c2.z);
+            L++;
+        }
+    }
+    ora_radix_sort(codes, vals, t1, t2, L);
+    if (codes_sorted) memcpy(codes_sorted, codes, (size_t)L * 4);
+    if (indices_sorted) memcpy(indices_sorted, vals, (size_t)L * 4);
+    /* GenerateTriangles with the pair branch (BottomUpBuilder.cu:294-309, CreateTrianglePair Pairing.cuh:60-77) */
+    for (uint32_t g = 0; g < L; g++) {
+        const uint32_t index = vals[g] & 0x7FFFFFFFu;
+        ora_triangle_pair r;
+        memset(&r, 0, sizeof r);
+        if (vals[g] >> 31) {
+            const ora_triangle *a = &tris[index], *b = &tris[index + 1];
+            int ra = 0, rb = 0;
+            can_form_pair(a, b, &ra, &rb);
+            ora_triangle ar = *a;                       /* RotateTriangle (:9-21) */
+            if (ra == 1) { ar.v0 = a->v2; ar.v1 = a->v0; ar.v2 = a->v1; }
+            else if (ra == 2) { ar.v0 = a->v1; ar.v1 = a->v2; ar.v2 = a->v0; }
+            r.v0 = ar.v0; r.v1 = ar.v1; r.v2 = ar.v2;
+            r.v3 = rb == 2 ? b->v0 : rb == 1 ? b->v1 : b->v2;
+            r.primitive_id_0 = index;
+            r.primitive_id_1 = index + 1;
+            r.rot_x = (uint16_t)ra;
+            r.rot_y = (uint16_t)rb;
+        } else {
+            r.v0 = tris[index].v0; r.v1 = tris[index].v1; r.v2 = tris[index].v2;
+            r.v3 = r.v2;
+            r.primitive_id_0 = index;
+        }
+        leaves[g] = r;
+    }
+    if (L == 1) {
+        ora_f3 bmin = min3(min3(min3(leaves[0].v0, leaves[0].v1), leaves[0].v2), leaves[0].v3);
+        ora_f3 bmax = max3(max3(max3(leaves[0].v0, leaves[0].v1), leaves[0].v2), leaves[0].v3);
+        nodes[0].min = bmin; nodes[0].max = bmax;
+        nodes[0].w12 = 1u << 29;
+        nodes[0].w28 = 0u | ((uint32_t)ORA_TYPE_TRI << 29);
+    } else {
+        ora_generate_hierarchy(nodes, t2, codes, L);
+        memset(t1, 0, (size_t)n * 4);
+        ora_generate_aabbs(nodes, t2, vals, t1, leaves, L);   /* includes v3 when the MSB of the value is set */
+    }
+    free(codes); free(vals); free(t1); free(t2);
+    return L;
+}
+
 /* ================================================================== hybrid top tree
  * ExtractDepth (BottomUpBuilder.cu:314-371): thread tid walks from pair 0 following bit d of tid at level d
  * (bit set -> the child of slot cur, bit clear -> the child of slot cur+1), 8 levels; a pair with a Tri slot stops

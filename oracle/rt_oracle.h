@@ -103,6 +103,15 @@ void ora_generate_aabbs(ora_node* nodes, const uint32_t* leaf_indices, const uin
 void ora_build(const ora_triangle* tris, uint32_t n, ora_node* nodes, ora_triangle_pair* leaves,
                uint32_t* codes_sorted, uint32_t* indices_sorted, int32_t* aabb_ordered);
 
+/* --pairs: GenerateMortonCodesPairs (BottomUpBuilder.cu:117-164) + Pairing.cuh:9-77 + the pair
+ * branches of GenerateTriangles / GenerateAABBs (:259-267, :301-303).  Triangles 2k, 2k+1 that share an edge (exact
+ * vertex equality) and pass ShouldFormTrianglePair become one quad leaf.  The reference claims leaf slots with
+ * atomicAdd (arrival order); here slot = exclusive prefix sum of the per-candidate leaf counts in input
+ * order, which makes the pre-sort order -- and so the whole tree -- deterministic.
+ * Same outputs as ora_build; returns the number of leaves L (<= n).  nodes: 2*max(n,1) slots, leaves: n entries. */
+uint32_t ora_build_pairs(const ora_triangle* tris, uint32_t n, ora_node* nodes, ora_triangle_pair* leaves,
+                         uint32_t* codes_sorted, uint32_t* indices_sorted, int32_t* aabb_ordered);
+
 /* Hybrid top tree: ExtractDepth (BottomUpBuilder.cu:314-371) + SharedTaskBuild as launched at
  * BuildWrapper.cu:350-361, restated DETERMINISTICALLY (the reference emits sub-roots and allocates nodes in
  * atomic-arrival order): sub-roots in ascending thread id; tasks processed first-in

@@ -166,8 +166,6 @@ def test_unsupported_options_fail_loudly(rt, scenes):
     tris = scenes.grid_mesh(4, 1)
     inp = rt.BuildInput.allocate(tris)
     with pytest.raises(rt.RtError):
-        rt.RunBottomUpBuild(inp, rt.Arguments(build_type=rt.kBottomUp, enable_pairs=True))
-    with pytest.raises(rt.RtError):
         rt.RunBottomUpBuild(inp, rt.Arguments(build_type=rt.kBottomUp, enable_splits=True))
 
 

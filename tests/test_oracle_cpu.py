@@ -228,3 +228,24 @@ def test_hybrid_top_tree_oracle(ora, scenes):
         i1, _ = ora.trace(b["leaves"], b["nodes"], 0, 2, cam, 96, 64)
         i2, _ = ora.trace(h["leaves"], h["nodes"], root, 2, cam, 96, 64)
         assert (i1 == i2).all()
+
+
+def test_pairs_oracle(ora, scenes):
+    """--pairs in the oracle: every grid cell merges into one quad leaf, unrelated triangles never merge, the tree
+    stays valid and renders exactly what the unpaired tree renders (depth and material id through RotateAttributes)."""
+    for tris, expect in ((scenes.grid_mesh(16, 2), 256), (scenes.soup(500, 1, dup_fraction=0.0), 500), (scenes.grid_mesh(4, 1)[:31], 16)):
+        p, b = ora.build_pairs(tris), ora.build_bvh(tris)
+        n, L = p["n"], p["L"]
+        assert L == expect and int((p["indices"] >> 31).sum()) == n - L
+        assert ora.verify_hierarchy(p["nodes"], 0, 2) == 0 and ora.count_nodes(p["nodes"], 0, 2) == (2 * L - 2, L, L - 2)
+        lv = p["leaves"]
+        pair = (p["indices"] >> 31) == 1
+        assert (lv["primitive_id_1"][pair] == lv["primitive_id_0"][pair] + 1).all() and (lv["v3"][~pair] == lv["v2"][~pair]).all()
+        lo, hi = ora.ordered_to_float(b["aabb"][:3]), ora.ordered_to_float(b["aabb"][3:])
+        cam = scenes.camera_for_box(lo, hi)
+        at = scenes.flat_attributes(tris, np.arange(n, dtype=np.int32) % 3)
+        mats = scenes.default_materials(3)
+        for rtype in (0, 3, 5):
+            i1, _ = ora.trace(b["leaves"], b["nodes"], 0, 2, cam, 96, 64, render_type=rtype, attributes=at, materials=mats, light=tuple(hi + 1))
+            i2, _ = ora.trace(p["leaves"], p["nodes"], 0, 2, cam, 96, 64, render_type=rtype, attributes=at, materials=mats, light=tuple(hi + 1))
+            assert (i1 == i2).all(), rtype
