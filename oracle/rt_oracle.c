@@ -772,6 +772,8 @@ static inline int intersect_ray_triangle_pair(const ora_triangle_pair* tp, ray_t
 /* Tracer.cu:308-374 TraceRay.  The reference prints "stack overflow" when stack_size reaches 64 and
  * then writes out of bounds; here a push at 64 is dropped (cannot happen on a binary LBVH, SURVEY A). */
 typedef struct { uint32_t index, count; } stack_entry_t;
+static uint32_t* g_visit_counts = 0;   /* analysis aid (tools/visit_histogram.py): per-slot visit counter, or NULL */
+void ora_set_visit_counts(uint32_t* p) { g_visit_counts = p; }
 #define PUSH(e) do { if (sp < 64) stack[sp++] = (e); if (sp > stats->max_stack) stats->max_stack = sp; } while (0)
 static int trace_ray(const ora_triangle_pair* leaves, const ora_node* nodes, uint32_t root, uint32_t count,
                      ray_t* ray, ray_result_t* rr, stats_t* stats)
@@ -783,6 +785,7 @@ static int trace_ray(const ora_triangle_pair* leaves, const ora_node* nodes, uin
     stack[0].count = count;
     while (sp) {
         stack_entry_t entry = stack[--sp];
+        if (g_visit_counts) __atomic_fetch_add(&g_visit_counts[entry.index], 1u, __ATOMIC_RELAXED);
         unsigned num_hits = 0;
         stack_entry_t child_buffer = {0, 0};
         float child_dist = 0.0f;

@@ -136,6 +136,9 @@ int ora_trace(const ora_triangle_pair* leaves, const ora_node* nodes, uint32_t r
               uint8_t* rgba8, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t spp,
               uint64_t* counters);
 
+/* analysis aid: when set, ora_trace adds 1 to p[first slot] for every sibling pair a ray visits */
+void ora_set_visit_counts(uint32_t* p);
+
 #ifdef __cplusplus
 }
 #endif
