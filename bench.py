@@ -69,10 +69,16 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
         if world == 1 and args.gpus > 1:
             sys.exit(2)
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev = local_rank % max(ndev, 1)          # (more ranks than GPUs only happens in the gloo rehearsal below)
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("RT_BENCH_BACKEND", "nccl")   # "gloo": rehearse the N > 1 control flow on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
 
     rt = importlib.import_module("gpu-raytracing_amd")
     scenes = importlib.import_module("gpu-raytracing_amd.scenes")
@@ -103,27 +109,44 @@ def main():
 
     cams = {"a": scenes.camera_a(G), "b": scenes.camera_b(G)}
     cam_dev = {k: rt.to_device(v) for k, v in cams.items()}
-    frame = torch.zeros(H * W * 4, dtype=torch.uint8, device="cuda")
+    # two frame buffers: with N > 1 the gather of frame i overlaps the trace of frame i+1 (double-buffered frames)
+    frames = [torch.zeros(H * W * 4, dtype=torch.uint8, device="cuda") for _ in range(2 if world > 1 else 1)]
+    frame = frames[0]
+    pending = [None, None]
     counters = torch.zeros(4, dtype=torch.int64, device="cuda")
 
     # row bands: rank r renders rows [r*H/N, (r+1)*H/N)  (gpu-raytracing_amd/sharding.py)
     sharding = importlib.import_module("gpu-raytracing_amd.sharding")
     y0, y1 = sharding.my_band(H, world, rank)
 
+    step_no = [0]
+
     def step(cam_key, with_counters=False, events=None):
+        k = step_no[0] % len(frames)
+        step_no[0] += 1
+        if pending[k] is not None:          # the gather that last used this buffer must have completed
+            pending[k].wait()
+            pending[k] = None
         if events is not None:
             events[0].record()
-        rt.Trace(inp.triangles_out, inp.nodes_out, frame, (W, H), cam_dev[cam_key], 0, 2,
+        rt.Trace(inp.triangles_out, inp.nodes_out, frames[k], (W, H), cam_dev[cam_key], 0, 2,
                  render_type=args.render_type, counters=counters if with_counters else None,
                  rows=(y0, y1), spp=args.spp)
         if events is not None:
             events[1].record()
         if world > 1:
-            sharding.gather_bands(frame, W, H, world, rank, dist)
+            pending[k] = sharding.gather_bands(frames[k], W, H, world, rank, dist, async_op=True)
+
+    def drain():
+        for k in range(len(pending)):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
 
     def timed(cam_key, steps, warmup):
         for _ in range(warmup):
             step(cam_key)
+        drain()
         evs = [(ev(), ev()) for _ in range(steps)]
         if world > 1:
             dist.barrier()
@@ -131,6 +154,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(steps):
             step(cam_key, events=evs[i])
+        drain()                              # every gather of the K timed frames has completed
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -145,6 +169,7 @@ def main():
     def test_counts(cam_key):
         counters.zero_()
         step(cam_key, with_counters=True)
+        drain()
         torch.cuda.synchronize()
         c = counters.clone()
         if world > 1:
@@ -195,7 +220,7 @@ def main():
             "config": {"workload": f"grid_mesh(G={G}, seed=1) = {n} triangles, {W}x{H}, {args.spp} spp, camera "
                                    f"{cam.upper()} ({'top-down' if cam == 'a' else 'oblique'}), render_type {args.render_type}; "
                                    "LBVH replicated per GPU",
-                       "parallelism": f"row-bands x{world}" + (" + RCCL gather to rank 0" if world > 1 else "")},
+                       "parallelism": f"row-bands x{world}" + (" + RCCL gather to rank 0, double-buffered frames" if world > 1 else "")},
             "box_tests_per_ray": round(box / rays, 2), "tri_tests_per_ray": round(tri / rays, 3),
             "wave_steps": {"box_phase": wsteps_box, "leaf_phase": wsteps_leaf,
                            "lane_utilisation_box_phase": round(box / 2 / max(wsteps_box, 1) / 64, 3)},

@@ -19,12 +19,15 @@ def my_band(height: int, world: int, rank: int) -> Tuple[int, int]:
     return b[rank], b[rank + 1]
 
 
-def gather_bands(frame, width: int, height: int, world: int, rank: int, dist=None, bytes_per_pixel: int = 4) -> None:
+def gather_bands(frame, width: int, height: int, world: int, rank: int, dist=None, bytes_per_pixel: int = 4,
+                 async_op: bool = False):
     """Collect every rank's rows into rank 0's `frame` (a flat uint8 tensor of width*height*bytes_per_pixel bytes,
     each rank having rendered its own rows in place).  Equal bands use one gather into views of rank 0's frame;
-    ragged bands (height % world != 0) fall back to point-to-point into place."""
+    ragged bands (height % world != 0) fall back to point-to-point into place.
+    async_op=True (equal bands only) returns the collective's work handle instead of waiting, so the caller can
+    trace the next frame into another buffer while this one is in flight."""
     if world == 1:
-        return
+        return None
     if dist is None:
         import torch.distributed as dist  # noqa: PLC0415
     b = band_bounds(height, world)
@@ -34,10 +37,11 @@ def gather_bands(frame, width: int, height: int, world: int, rank: int, dist=Non
     if rank == 0:
         views = [frame[b[r] * row:b[r + 1] * row] for r in range(world)]
     if len({b[r + 1] - b[r] for r in range(world)}) == 1:
-        dist.gather(band, views, dst=0)
-    elif rank == 0:
+        return dist.gather(band, views, dst=0, async_op=async_op)
+    if rank == 0:
         reqs = [dist.irecv(views[r], src=r) for r in range(1, world)]
         for q in reqs:
             q.wait()
     else:
         dist.send(band, dst=0)
+    return None

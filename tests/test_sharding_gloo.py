@@ -31,7 +31,9 @@ def _worker(rank, world, port, w, h, out_path):
     y0, y1 = sharding.my_band(h, world, rank)
     img, cnt = ora.trace(b["leaves"], b["nodes"], 0, 2, cam, w, h, rows=(y0, y1))
     frame = torch.from_numpy(img.reshape(-1).copy())
-    sharding.gather_bands(frame, w, h, world, rank, dist)
+    work = sharding.gather_bands(frame, w, h, world, rank, dist, async_op=True)   # bench.py's double-buffered form
+    if work is not None:
+        work.wait()
     c = torch.tensor([int(cnt[0]), int(cnt[1])])
     dist.all_reduce(c)
     if rank == 0:
