@@ -200,7 +200,32 @@ __device__ __forceinline__ bool trace_ray(const TraceParams& p, Ray& r, Hit& h, 
             stepping = __builtin_amdgcn_ballot_w64(t.phase == PH_STEP);
             parked = __builtin_amdgcn_ballot_w64((t.phase - 1u) < 2u);
             if (stepping == 0 || __popcll(stepping) * p.park_den < __popcll(parked) * p.park_num) break;
-            nbox++;
+            nbox += 2;   // two box steps per vote (below)
+            if (t.phase == PH_STEP) {
+                const uint32_t cnt = t.cur >> 29;
+                const uint4* np = reinterpret_cast<const uint4*>(p.nodes + (t.cur & kIndexMask));
+                const bool two = cnt > 1;
+                const int o1 = two ? 2 : 0;  // all four loads issue together; a lone slot is simply read twice
+                const uint4 a0 = np[0], b0 = np[1], a1 = np[o1], b1 = np[o1 + 1];
+                float f0, k0;
+                slab(a0, b0, r, f0, k0);
+                slab(a1, b1, r, t.f1, t.k1);
+                t.e1 = (b1.w & kIndexMask) | (a1.w & ~kIndexMask);
+                t.t1 = two ? (b1.w >> 29) : (uint32_t)RT_CHILD_NONE;
+                const uint32_t type0 = b0.w >> 29;
+                const uint32_t e0 = (b0.w & kIndexMask) | (a0.w & ~kIndexMask);
+                const bool valid0 = type0 != RT_CHILD_NONE;
+                const bool hit0 = valid0 & (k0 >= f0) & (f0 <= r.tmax) & (k0 >= r.tmin);
+                t.box_tests += valid0 ? 1u : 0u;
+                const bool leaf0 = hit0 & (type0 == RT_CHILD_TRI);
+                t.inner_hit(hit0 & !leaf0, e0, f0);
+                if (leaf0) { t.leaf = e0; t.phase = PH_LEAF0; }
+                else {
+                    t.second_slot(r.tmin, r.tmax);
+                    if (t.phase == PH_STEP) t.advance();
+                }
+            }
+            // second step under the same vote: halves the per-step loop overhead (ballots, branch, copies)
             if (t.phase == PH_STEP) {
                 const uint32_t cnt = t.cur >> 29;
                 const uint4* np = reinterpret_cast<const uint4*>(p.nodes + (t.cur & kIndexMask));
