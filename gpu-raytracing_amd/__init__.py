@@ -71,6 +71,17 @@ class _Scene(ctypes.Structure):
                 ("num_textures", ctypes.c_uint32)]
 
 
+NUM_LODS = 13  # Common.cuh:17
+
+
+class _Texture(ctypes.Structure):  # rt_texture
+    _fields_ = [("mips", ctypes.c_void_p * NUM_LODS), ("size_x", ctypes.c_int32 * NUM_LODS),
+                ("size_y", ctypes.c_int32 * NUM_LODS), ("max_lod", ctypes.c_uint32), ("pad", ctypes.c_uint32)]
+
+
+assert ctypes.sizeof(_Texture) == 216
+
+
 class _ScratchLayout(ctypes.Structure):
     _fields_ = [("p_aabb", ctypes.c_size_t), ("status", ctypes.c_size_t), ("num_leaves", ctypes.c_size_t),
                 ("morton", ctypes.c_size_t),
@@ -239,16 +250,39 @@ def RadixSortScratchBytes(count: int) -> int:
     return int(lib().rt_radix_sort_scratch_bytes(count))
 
 
+class DeviceTextures:
+    """The device-side Texture table of DeviceScene (Common.cuh:342-351, uploaded by main.cu:100-113): one
+    rt_texture per texture, mips in device memory.  `chains` is a list of mip chains, each a list of [sy, sx]
+    uint32 arrays (r | g<<8 | b<<16 | a<<24), level 0 first."""
+
+    def __init__(self, chains, device="cuda"):
+        table = (_Texture * max(1, len(chains)))()
+        self._mips = []
+        for t, chain in enumerate(chains):
+            if not 1 <= len(chain) <= NUM_LODS:
+                raise ValueError("a texture has 1..13 mip levels")
+            for l, m in enumerate(chain):
+                m = np.ascontiguousarray(m, np.uint32)
+                d = to_device(m, device)
+                self._mips.append(d)
+                table[t].mips[l] = _ptr(d)
+                table[t].size_x[l], table[t].size_y[l] = m.shape[1], m.shape[0]
+            table[t].max_lod = len(chain) - 1
+        self.count = len(chains)
+        self.table = to_device(np.frombuffer(bytes(table), np.uint8).copy(), device)
+
+
 def Trace(triangles, nodes, rgba8, dims, camera, root: int, count: int, *, render_type: int = kDepth,
           attributes=None, materials=None, num_materials: int = 0, light=(0.0, 0.0, 0.0), counters=None,
-          rows=None, spp: int = 1, stream=None) -> None:
+          rows=None, spp: int = 1, stream=None, textures: Optional[DeviceTextures] = None) -> None:
     """main.cu:125-192 Trace(): `camera` is a 64-byte DEVICE buffer, `rgba8` a w*h*4-byte device buffer
     (the reference writes a GL surface; row 0 first).  rows=(y0, y1) restricts to a row band (multi-GPU tiling)."""
     w, h = int(dims[0]), int(dims[1])
     y0, y1 = (0, h) if rows is None else (int(rows[0]), int(rows[1]))
     a = _Accel(_ptr(triangles), _ptr(nodes), root, count)
-    s = _Scene(_ptr(attributes), _ptr(materials), 0, _ptr(camera), (ctypes.c_float * 3)(*[float(x) for x in light]),
-               0, num_materials, 0)
+    s = _Scene(_ptr(attributes), _ptr(materials), _ptr(textures.table) if textures is not None else 0, _ptr(camera),
+               (ctypes.c_float * 3)(*[float(x) for x in light]),
+               0, num_materials, textures.count if textures is not None else 0)
     _check(lib().rt_trace(ctypes.byref(a), ctypes.byref(s), _ptr(counters), render_type, _ptr(rgba8), w, h, y0, y1,
                           spp, _stream_ptr(stream)), "rt_trace")
 

@@ -150,7 +150,11 @@ int rt_trace(const rt_accel* as, const rt_scene* scene, uint64_t* counters, int 
     case RT_RENDER_MATERIAL_ID: case RT_RENDER_DIFFUSE:
         if (!scene->attributes || !scene->materials || scene->num_materials == 0) return RT_ERR_INVALID_ARGUMENT;
         break;
-    default: return RT_ERR_UNSUPPORTED;  // textured modes: SURVEY 8(f) rank 2
+    case RT_RENDER_LODS: case RT_RENDER_TEXTURE: case RT_RENDER_TEXTURE_LIT: case RT_RENDER_TEXTURE_LIT_SHADOWS:
+        if (!scene->attributes || !scene->materials || scene->num_materials == 0) return RT_ERR_INVALID_ARGUMENT;
+        if (scene->num_textures && !scene->textures) return RT_ERR_INVALID_ARGUMENT;
+        break;
+    default: return RT_ERR_INVALID_ARGUMENT;
     }
     TraceLaunch t;
     t.as = *as;

@@ -13,6 +13,7 @@ static_assert(sizeof(rt_triangle_pair) == 64, "TrianglePair layout (Common.cuh:1
 static_assert(sizeof(rt_camera) == 64, "Camera layout (Common.cuh:44)");
 static_assert(sizeof(rt_attributes) == 72, "Attributes layout (Common.cuh:55)");
 static_assert(sizeof(rt_material) == 52, "Material POD mirror");
+static_assert(sizeof(rt_texture) == 216, "Texture POD mirror");
 
 namespace rt {
 

@@ -55,6 +55,7 @@ struct TraceParams {
     const rt_triangle_pair* leaves;
     const rt_attributes* attributes;
     const rt_material* materials;
+    const rt_texture* textures;
     const rt_camera* camera;
     float light[3];
     uint32_t root, count, num_materials;
@@ -303,12 +304,137 @@ __device__ __forceinline__ void hsv_to_rgb255(float h, float s, float v, float& 
     R = (r + m) * 255; G = (g + m) * 255; B = (b + m) * 255;
 }
 
-// one sample of one pixel -> float colour 0..255 per channel (TraceRays body, Tracer.cu:482-593).
-// Every lane of the wave calls this (inactive lanes trace nothing) because trace_ray votes with ballots.
+// ---------------------------------------------------------------------------------------------
+// float -> unsigned char as CUDA converts it (cvt.rzi.u8.f32: NaN -> 0, saturating); bilinear weights at a texture
+// border leave [0, 255]
+__device__ __forceinline__ uint32_t sat_u8(float v) { return !(v > 0.0f) ? 0u : (v >= 255.0f ? 255u : (uint32_t)v); }
+struct F2 { float x, y; };
+struct U8x4 { uint32_t c[4]; };
+__device__ __forceinline__ float fracf1(float v) { return v - floorf(v); }   // helper_math.h:1367
+
+// Sample(Texture&, int2, lod) (Tracer.cu:103-108)
+__device__ __forceinline__ void tex_fetch(const rt_texture& t, int x, int y, int lod, float out[4])
+{
+    const int sx = t.size_x[lod], sy = t.size_y[lod];
+    x = max(0, min(x, sx - 1));
+    y = max(0, min(y, sy - 1));
+    const uint32_t w = t.mips[lod][(size_t)y * sx + x];
+    out[0] = (float)(w & 255u); out[1] = (float)((w >> 8) & 255u); out[2] = (float)((w >> 16) & 255u); out[3] = (float)(w >> 24);
+}
+// BilinearSample (Tracer.cu:122-140)
+__device__ __forceinline__ U8x4 bilinear_sample(const rt_texture& t, F2 uv, int lod)
+{
+    float cx = fracf1(uv.x) * (float)t.size_x[lod] - 0.5f;
+    float cy = fracf1(uv.y) * (float)t.size_y[lod] - 0.5f;
+    cy = (float)t.size_y[lod] - cy;
+    const int ix = (int)cx, iy = (int)cy;
+    const float dx = cx - (float)ix, dy = cy - (float)iy;
+    const float w0 = (1.0f - dx) * dy, w1 = dx * dy, w2 = (1.0f - dx) * (1.0f - dy), w3 = dx * (1.0f - dy);
+    float s0[4], s1[4], s2[4], s3[4];
+    tex_fetch(t, ix, iy, lod, s0);
+    tex_fetch(t, ix + 1, iy, lod, s1);
+    tex_fetch(t, ix, iy - 1, lod, s2);
+    tex_fetch(t, ix + 1, iy - 1, lod, s3);
+    U8x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; c++) o.c[c] = sat_u8(((s0[c] * w0 + s1[c] * w1) + s2[c] * w2) + s3[c] * w3);
+    return o;
+}
+// TrilinearSample (Tracer.cu:142-155)
+__device__ __forceinline__ U8x4 trilinear_sample(const rt_texture& t, F2 uv, float lod)
+{
+    uint32_t min_lod = (uint32_t)floorf(lod), max_lod = min_lod + 1;
+    min_lod = min(min_lod, t.max_lod);
+    max_lod = min(max_lod, t.max_lod);
+    const U8x4 a = bilinear_sample(t, uv, (int)min_lod), b = bilinear_sample(t, uv, (int)max_lod);
+    const float frac = fracf1(lod);
+    U8x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; c++) o.c[c] = sat_u8((float)a.c[c] * (1.0f - frac) + (float)b.c[c] * frac);
+    return o;
+}
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 vsub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 vadd(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 vscale(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ float vdot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 vcross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ V3 vnormalize(V3 v) { return vscale(v, 1.0f / sqrtf(vdot(v, v))); }
+
+struct Surface {   // what the textured shaders need about the hit
+    V3 tri[3];
+    float uv[3][2];
+    V3 n[3];
+};
+__device__ __forceinline__ F2 interp_uv(const Surface& s, float bu, float bv)   // InterpolateUVs (Tracer.cu:43-48)
+{
+    const float w0 = 1 - bu - bv;
+    return {(s.uv[0][0] * w0 + s.uv[1][0] * bu) + s.uv[2][0] * bv, (s.uv[0][1] * w0 + s.uv[1][1] * bu) + s.uv[2][1] * bv};
+}
+// ComputeLOD (Tracer.cu:237-254) with RayTriangleGradients (:202-235) inlined
+__device__ __forceinline__ float compute_lod(const Ray& r, const Hit& h, float spread, const Surface& s, const rt_texture& tex)
+{
+    const V3 o = v3(r.ox, r.oy, r.oz), d = v3(r.dx, r.dy, r.dz);
+    const V3 edge1 = vsub(s.tri[1], s.tri[0]), edge2 = vsub(s.tri[2], s.tri[0]);
+    const V3 sv = vsub(o, s.tri[0]);
+    const V3 q = vcross(sv, edge1);
+    const V3 x = vscale(vscale(vnormalize(vcross(d, v3(0, 1, 0))), r.tmax), spread);
+    const V3 y = vscale(vscale(vnormalize(vcross(d, x)), r.tmax), spread);
+    const V3 hit_point = vadd(o, vscale(d, r.tmax));
+    const V3 dirx = vnormalize(vsub(vadd(hit_point, x), o)), diry = vnormalize(vsub(vadd(hit_point, y), o));
+    const V3 h0 = vcross(dirx, edge2);
+    const float f0 = 1.0f / vdot(edge1, h0);
+    const float bu0 = f0 * vdot(sv, h0), bv0 = f0 * vdot(dirx, q);
+    const V3 h1 = vcross(diry, edge2);
+    const float f1 = 1.0f / vdot(edge1, h1);
+    const float bu1 = f1 * vdot(sv, h1), bv1 = f1 * vdot(diry, q);
+    const F2 uvs = interp_uv(s, h.bu, h.bv), ux = interp_uv(s, bu0, bv0), uy = interp_uv(s, bu1, bv1);
+    const float sx = (float)tex.size_x[0], sy = (float)tex.size_y[0];
+    const float dxx = fabsf(ux.x - uvs.x) * sx, dxy = fabsf(ux.y - uvs.y) * sy;
+    const float dyx = fabsf(uy.x - uvs.x) * sx, dyy = fabsf(uy.y - uvs.y) * sy;
+    const float max_change = fmaxf(sqrtf(dxx * dxx + dxy * dxy), sqrtf(dyx * dyx + dyy * dyy));
+    return fmaxf(0.0f, fminf(log2f(max_change), (float)tex.max_lod));
+}
+// TangentMatrix (Tracer.cu:84-101)
+__device__ __forceinline__ void tangent_matrix(const Surface& s, V3 rows[3])
+{
+    const V3 e1 = vsub(s.tri[1], s.tri[0]), e2 = vsub(s.tri[2], s.tri[0]);
+    const float d1x = s.uv[1][0] - s.uv[0][0], d1y = s.uv[1][1] - s.uv[0][1];
+    const float d2x = s.uv[2][0] - s.uv[0][0], d2y = s.uv[2][1] - s.uv[0][1];
+    const float f = 1.0f / (d1x * d2y - d1y * d2x);
+    const V3 normal = vnormalize(vcross(e1, e2));
+    const V3 tangent = vnormalize(vscale(vsub(vscale(e1, d2y), vscale(e2, d1y)), f));
+    const V3 bitangent = vnormalize(vscale(vsub(vscale(e2, d1x), vscale(e1, d2x)), f));
+    rows[0] = v3(tangent.x, bitangent.x, normal.x);
+    rows[1] = v3(tangent.y, bitangent.y, normal.y);
+    rows[2] = v3(tangent.z, bitangent.z, normal.z);
+}
+// Bump2Normal (Tracer.cu:157-185)
+__device__ __forceinline__ V3 bump2normal(const rt_texture& tex, const V3 tbn[3], F2 uv, float lod)
+{
+    const float texel_step = powf(2.0f, lod);
+    const float stx = texel_step / (float)tex.size_x[0], sty = texel_step / (float)tex.size_y[0];
+    const U8x4 a = trilinear_sample(tex, F2{uv.x - stx * 0.5f, uv.y - sty * 0.5f}, lod);
+    const U8x4 b = trilinear_sample(tex, F2{uv.x + stx * 0.5f, uv.y + 0.0f}, lod);
+    const U8x4 c = trilinear_sample(tex, F2{uv.x + 0.0f, uv.y + sty * 0.5f}, lod);
+    const float gx = (float)b.c[0] - (float)a.c[0], gy = (float)c.c[0] - (float)a.c[0];
+    const float d = 4.0f;
+    V3 n = vnormalize(vcross(v3(1, 0, d * gx / (texel_step * 256.0f)), v3(0, 1, d * gy / (texel_step * 256.0f))));
+    n = v3(vdot(tbn[0], n), vdot(tbn[1], n), vdot(tbn[2], n));
+    return vnormalize(n);
+}
+
+constexpr bool render_is_lit(int r) { return r == RT_RENDER_DIFFUSE || r == RT_RENDER_TEXTURE_LIT || r == RT_RENDER_TEXTURE_LIT_SHADOWS; }
+constexpr bool render_uses_surface(int r) { return r == RT_RENDER_LODS || r == RT_RENDER_TEXTURE || r == RT_RENDER_TEXTURE_LIT || r == RT_RENDER_TEXTURE_LIT_SHADOWS; }
+
+// one sample of one pixel -> float colour 0..255 per channel + alpha (TraceRays body, Tracer.cu:482-593).
+// Every lane of the wave calls this (inactive lanes trace nothing) because trace_ray votes with ballots; the shadow
+// ray of kTextureLitShadows is a second wave-level traversal over the lanes that hit something.
 template <int RENDER>
 __device__ __forceinline__ void shade_sample(const TraceParams& p, const rt_camera& cam, uint32_t x, uint32_t y,
                                              float ox, float oy, Trav& t, bool active, uint32_t& box_acc,
-                                             uint32_t& tri_acc, uint32_t* steps, float& R, float& G, float& B)
+                                             uint32_t& tri_acc, uint32_t* steps, float& R, float& G, float& B, float& A)
 {
     const float ndcx = 2 * (((float)x + ox) / (float)p.w) - 1;
     const float ndcy = 2 * (((float)y + oy) / (float)p.h) - 1;
@@ -325,65 +451,147 @@ __device__ __forceinline__ void shade_sample(const TraceParams& p, const rt_came
     r.tmax = max_depth;
     Hit h = {0u, 0u, 0.f, 0.f};
     const bool hit = trace_ray(p, r, h, t, active, steps);
-    box_acc += t.box_tests;
-    tri_acc += t.tri_tests;
+    const uint32_t box_tests = t.box_tests, tri_tests = t.tri_tests;
+    box_acc += box_tests;
+    tri_acc += tri_tests;
     const float depth = hit ? r.tmax : 0.0f;
     R = G = B = 0;
-    if (!active) return;
+    A = 255.0f;
 
     if (RENDER == RT_RENDER_DEPTH) {
         R = G = B = fminf(1.0f, depth / max_depth) * 255;
         return;
     }
     if (RENDER == RT_RENDER_BOXTESTS) {
-        G = B = fminf(t.box_tests / 180.0f, 1.0f) * 255;
+        G = B = fminf(box_tests / 180.0f, 1.0f) * 255;
         return;
     }
     if (RENDER == kRenderDebugBoxCount) {  // tuning aid: R carries the raw count (bit pattern), see trace_kernel
-        R = __uint_as_float(t.box_tests);
+        R = __uint_as_float(box_tests);
         return;
     }
     if (RENDER == RT_RENDER_TRIANGLE_TESTS) {
-        const float g = fminf(t.tri_tests / 32.0f, 1.0f);
+        const float g = fminf(tri_tests / 32.0f, 1.0f);
         R = g * 100; G = g * 255; B = g * 100;
         return;
     }
-    if (!hit) return;
-    // RotateAttributes (Tracer.cu:57-82)
-    const rt_triangle_pair* pair = p.leaves + (h.tri_id >> 1);
-    const uint32_t rot = (h.tri_id & 1) ? pair->rotations[1] : pair->rotations[0];
-    const rt_attributes* at = p.attributes + h.primitive_id;
-    const int i0 = rot == 1 ? 2 : (rot == 2 ? 1 : 0);
-    const int i1 = rot == 1 ? 0 : (rot == 2 ? 2 : 1);
-    const int i2 = rot == 1 ? 1 : (rot == 2 ? 0 : 2);
-    const int material_id = at->material_id;
-    if (RENDER == RT_RENDER_MATERIAL_ID) {
-        hsv_to_rgb255((float)material_id / p.num_materials, 1.0f, 1.0f, R, G, B);
+    // ---- modes that look at the surface.  The reference fetches attributes / material before testing `hit`
+    // (Tracer.cu:506-509: primitive 0 on a miss); only kLODs depends on that (magenta unless textured AND hit).
+    const bool lit = active && hit;
+    const bool fetch = active && (hit || RENDER == RT_RENDER_LODS);
+    rt_material mat = {};
+    Surface s = {};
+    int material_id = 0;
+    if (fetch) {
+        // RotateAttributes (Tracer.cu:57-82)
+        const rt_triangle_pair* pair = p.leaves + (h.tri_id >> 1);
+        const bool second = h.tri_id & 1;
+        const uint32_t rot = second ? pair->rotations[1] : pair->rotations[0];
+        const rt_attributes* at = p.attributes + h.primitive_id;
+        const int i0 = rot == 1 ? 2 : (rot == 2 ? 1 : 0);
+        const int i1 = rot == 1 ? 0 : (rot == 2 ? 2 : 1);
+        const int i2 = rot == 1 ? 1 : (rot == 2 ? 0 : 2);
+        material_id = at->material_id;
+        mat = p.materials[material_id];
+        const rt_float3 n0 = at->normal[i0], n1 = at->normal[i1], n2 = at->normal[i2];
+        s.n[0] = v3(n0.x, n0.y, n0.z); s.n[1] = v3(n1.x, n1.y, n1.z); s.n[2] = v3(n2.x, n2.y, n2.z);
+        if (render_uses_surface(RENDER)) {
+            s.uv[0][0] = at->uv[i0][0]; s.uv[0][1] = at->uv[i0][1];
+            s.uv[1][0] = at->uv[i1][0]; s.uv[1][1] = at->uv[i1][1];
+            s.uv[2][0] = at->uv[i2][0]; s.uv[2][1] = at->uv[i2][1];
+            const rt_float3 a = second ? pair->v2 : pair->v0, b = pair->v1, c = second ? pair->v3 : pair->v2;
+            s.tri[0] = v3(a.x, a.y, a.z); s.tri[1] = v3(b.x, b.y, b.z); s.tri[2] = v3(c.x, c.y, c.z);
+        }
+    }
+    const float spread = 2.0f / p.w;
+    if (RENDER == RT_RENDER_LODS) {                       // Tracer.cu:543-556
+        if (!active) return;
+        if (mat.texture != -1 && hit) {
+            const float lod = compute_lod(r, h, spread, s, p.textures[mat.texture]);
+            R = G = B = A = (float)(((uint32_t)((int)lod * 20)) & 255u);
+        } else {
+            R = 255; G = 0; B = 255;
+        }
         return;
     }
-    // kDiffuse: AmbientShader(use_textures = use_shadows = use_bump = false) (Tracer.cu:376-469)
-    const rt_material mat = p.materials[material_id];
-    const rt_float3 n0 = at->normal[i0], n1 = at->normal[i1], n2 = at->normal[i2];
+    if (RENDER == RT_RENDER_MATERIAL_ID) {
+        if (lit) hsv_to_rgb255((float)material_id / p.num_materials, 1.0f, 1.0f, R, G, B);
+        return;
+    }
+    if (RENDER == RT_RENDER_TEXTURE) {                    // Tracer.cu:557-578
+        if (!lit) return;
+        if (mat.texture != -1) {
+            const rt_texture& tex = p.textures[mat.texture];
+            const float lod = compute_lod(r, h, spread, s, tex);
+            const U8x4 c = trilinear_sample(tex, interp_uv(s, h.bu, h.bv), lod);
+            R = (float)c.c[0]; G = (float)c.c[1]; B = (float)c.c[2]; A = (float)c.c[3];
+        } else {
+            R = mat.diffuse.x * 255; G = mat.diffuse.y * 255; B = mat.diffuse.z * 255;
+        }
+        return;
+    }
+    // ---- AmbientShader (Tracer.cu:376-469): kDiffuse (no textures), kTextureLit (textures + bump), kTextureLitShadows
+    constexpr bool use_textures = RENDER == RT_RENDER_TEXTURE_LIT || RENDER == RT_RENDER_TEXTURE_LIT_SHADOWS;
+    constexpr bool use_bump = use_textures;
+    constexpr bool use_shadows = RENDER == RT_RENDER_TEXTURE_LIT_SHADOWS;
     const float hx = r.ox + r.dx * r.tmax, hy = r.oy + r.dy * r.tmax, hz = r.oz + r.dz * r.tmax;
-    const float w0 = 1 - h.bu - h.bv;
-    const float nx = (n0.x * w0 + n1.x * h.bu) + n2.x * h.bv;
-    const float ny = (n0.y * w0 + n1.y * h.bu) + n2.y * h.bv;
-    const float nz = (n0.z * w0 + n1.z * h.bu) + n2.z * h.bv;
     float lx = p.light[0] - hx, ly = p.light[1] - hy, lz = p.light[2] - hz;
-    const float linv = 1.0f / sqrtf(lx * lx + ly * ly + lz * lz);
+    const float to_light = sqrtf(lx * lx + ly * ly + lz * lz);      // length(light_pos - hit_pos) (:455)
+    const float linv = 1.0f / to_light;
     lx *= linv; ly *= linv; lz *= linv;
+    bool shadowed = false;
+    if (use_shadows) {                                    // (:447-462) a second traversal, wave-wide
+        Ray sr;
+        sr.ox = hx; sr.oy = hy; sr.oz = hz;
+        sr.dx = lx; sr.dy = ly; sr.dz = lz;
+        sr.ix = 1.0f / lx; sr.iy = 1.0f / ly; sr.iz = 1.0f / lz;
+        sr.tmin = 0.001f;
+        sr.tmax = to_light;
+        Hit sh = {0u, 0u, 0.f, 0.f};
+        shadowed = trace_ray(p, sr, sh, t, lit, steps);   // its test counts are not reported (shadow_stats, :451)
+    }
+    if (!lit) return;
+    const float w0 = 1 - h.bu - h.bv;
+    V3 n = vadd(vadd(vscale(s.n[0], w0), vscale(s.n[1], h.bu)), vscale(s.n[2], h.bv));   // InterpolateNormals (:50-56)
+    if (use_bump && mat.disp != -1) {                     // displacement map read as a normal map (:388-403)
+        const rt_texture& disp = p.textures[mat.disp];
+        const float lod = compute_lod(r, h, spread, s, disp);
+        V3 tbn[3];
+        tangent_matrix(s, tbn);
+        const U8x4 smp = trilinear_sample(disp, interp_uv(s, h.bu, h.bv), lod);
+        n = v3((float)smp.c[0] / 255.0f, (float)smp.c[1] / 255.0f, (float)smp.c[2] / 255.0f);
+        n = vnormalize(v3(n.x * 2.0f - 1.0f, n.y * 2.0f - 1.0f, n.z * 2.0f - 1.0f));
+        n = vnormalize(v3(vdot(tbn[0], n), vdot(tbn[1], n), vdot(tbn[2], n)));
+    } else if (use_bump && mat.bump != -1) {              // (:405-415)
+        const rt_texture& bump = p.textures[mat.bump];
+        const float lod = compute_lod(r, h, spread, s, bump);
+        V3 tbn[3];
+        tangent_matrix(s, tbn);
+        n = bump2normal(bump, tbn, interp_uv(s, h.bu, h.bv), lod);
+    }
+    const float nx = n.x, ny = n.y, nz = n.z;
     const float lcx = 1.0f, lcy = 0.9f, lcz = 0.8f;
-    const float dterm = 1.0f * fmaxf(nx * lx + ny * ly + nz * lz, 0.0f);
+    float dterm = 1.0f * fmaxf(nx * lx + ny * ly + nz * lz, 0.0f);
     // reflect(-l, n) = -l - 2.0f * n * dot(n, -l)   (helper_math.h:1435-1438)
     const float nlx = -lx, nly = -ly, nlz = -lz;
     const float ndl = nx * nlx + ny * nly + nz * nlz;
     const float rx = nlx - (nx * 2.0f) * ndl, ry = nly - (ny * 2.0f) * ndl, rz = nlz - (nz * 2.0f) * ndl;
     // pow(max(dot(-dir, refl), 0.0), Ns): double max, double pow, narrowed by operator*(float, float3)
     const double sb = fmax((double)((-r.dx) * rx + (-r.dy) * ry + (-r.dz) * rz), 0.0);
-    const float sp = (float)(1.0f * pow(sb, (double)mat.specular_exp));
-    float cr = ((lcx * dterm) * mat.diffuse.x + (lcx * 0.2f) * mat.ambient.x) + (lcx * sp) * mat.specular.x;
-    float cg = ((lcy * dterm) * mat.diffuse.y + (lcy * 0.2f) * mat.ambient.y) + (lcy * sp) * mat.specular.y;
-    float cb = ((lcz * dterm) * mat.diffuse.z + (lcz * 0.2f) * mat.ambient.z) + (lcz * sp) * mat.specular.z;
+    float sp = (float)(1.0f * pow(sb, (double)mat.specular_exp));
+    float odx = mat.diffuse.x, ody = mat.diffuse.y, odz = mat.diffuse.z;
+    if (use_textures && mat.texture != -1) {              // (:432-445): BilinearSample(tex, uv, (int)lod)
+        const rt_texture& tex = p.textures[mat.texture];
+        const float lod = compute_lod(r, h, spread, s, tex);
+        const U8x4 smp = bilinear_sample(tex, interp_uv(s, h.bu, h.bv), (int)lod);
+        odx = (float)smp.c[0] / 255; ody = (float)smp.c[1] / 255; odz = (float)smp.c[2] / 255;
+    }
+    float dfx = lcx * dterm, dfy = lcy * dterm, dfz = lcz * dterm;
+    float spx = lcx * sp, spy = lcy * sp, spz = lcz * sp;
+    if (shadowed) { dfx = dfy = dfz = 0.0f; spx = spy = spz = 0.0f; }
+    const float cr = (dfx * odx + (lcx * 0.2f) * mat.ambient.x) + spx * mat.specular.x;
+    const float cg = (dfy * ody + (lcy * 0.2f) * mat.ambient.y) + spy * mat.specular.y;
+    const float cb = (dfz * odz + (lcz * 0.2f) * mat.ambient.z) + spz * mat.specular.z;
     R = clampf(cr, 0.0f, 1.0f) * 255;
     G = clampf(cg, 0.0f, 1.0f) * 255;
     B = clampf(cb, 0.0f, 1.0f) * 255;
@@ -415,20 +623,20 @@ __global__ __launch_bounds__(kTraceWaves * 64, RT_TRACE_MIN_WAVES) void trace_ke
     t.spill = spill;
     uint32_t box_acc = 0, tri_acc = 0;
     uint32_t steps[2] = {0u, 0u};
-    float R, G, B;
+    float R, G, B, A;
     if (p.spp <= 1) {
-        shade_sample<RENDER>(p, cam, x, y, 0.5f, 0.5f, t, active, box_acc, tri_acc, steps, R, G, B);
+        shade_sample<RENDER>(p, cam, x, y, 0.5f, 0.5f, t, active, box_acc, tri_acc, steps, R, G, B, A);
     } else {
-        float ar = 0, ag = 0, ab = 0;
+        float ar = 0, ag = 0, ab = 0, aa = 0;
         for (uint32_t s = 0; s < p.spp; s++) {
             const float ox = ((float)(s % 4) + 0.5f) / 4.0f, oy = ((float)((s / 4) % 4) + 0.5f) / 4.0f;
-            shade_sample<RENDER>(p, cam, x, y, ox, oy, t, active, box_acc, tri_acc, steps, R, G, B);
-            ar += R; ag += G; ab += B;
+            shade_sample<RENDER>(p, cam, x, y, ox, oy, t, active, box_acc, tri_acc, steps, R, G, B, A);
+            ar += R; ag += G; ab += B; aa += A;
         }
-        R = ar / (float)p.spp; G = ag / (float)p.spp; B = ab / (float)p.spp;
+        R = ar / (float)p.spp; G = ag / (float)p.spp; B = ab / (float)p.spp; A = aa / (float)p.spp;
     }
     if (active) {
-        uint32_t px = (uint32_t)(uint8_t)R | ((uint32_t)(uint8_t)G << 8) | ((uint32_t)(uint8_t)B << 16) | 0xFF000000u;
+        uint32_t px = sat_u8(R) | (sat_u8(G) << 8) | (sat_u8(B) << 16) | (sat_u8(A) << 24);
         if (RENDER == kRenderDebugBoxCount) px = __float_as_uint(R);
         reinterpret_cast<uint32_t*>(p.rgba8)[(size_t)y * p.w + x] = px;
     }
@@ -451,6 +659,7 @@ hipError_t launch_trace(const TraceLaunch& t, hipStream_t st)
     p.leaves = t.as.triangles;
     p.attributes = t.scene.attributes;
     p.materials = t.scene.materials;
+    p.textures = t.scene.textures;
     p.camera = t.scene.camera;
     p.light[0] = t.scene.light[0]; p.light[1] = t.scene.light[1]; p.light[2] = t.scene.light[2];
     p.root = t.as.root;
@@ -480,6 +689,10 @@ hipError_t launch_trace(const TraceLaunch& t, hipStream_t st)
     case RT_RENDER_TRIANGLE_TESTS: trace_kernel<RT_RENDER_TRIANGLE_TESTS><<<grid, block, 0, st>>>(p); break;
     case RT_RENDER_MATERIAL_ID: trace_kernel<RT_RENDER_MATERIAL_ID><<<grid, block, 0, st>>>(p); break;
     case RT_RENDER_DIFFUSE: trace_kernel<RT_RENDER_DIFFUSE><<<grid, block, 0, st>>>(p); break;
+    case RT_RENDER_LODS: trace_kernel<RT_RENDER_LODS><<<grid, block, 0, st>>>(p); break;
+    case RT_RENDER_TEXTURE: trace_kernel<RT_RENDER_TEXTURE><<<grid, block, 0, st>>>(p); break;
+    case RT_RENDER_TEXTURE_LIT: trace_kernel<RT_RENDER_TEXTURE_LIT><<<grid, block, 0, st>>>(p); break;
+    case RT_RENDER_TEXTURE_LIT_SHADOWS: trace_kernel<RT_RENDER_TEXTURE_LIT_SHADOWS><<<grid, block, 0, st>>>(p); break;
     case kRenderDebugBoxCount: trace_kernel<kRenderDebugBoxCount><<<grid, block, 0, st>>>(p); break;
     default: return hipErrorInvalidValue;
     }

@@ -56,9 +56,24 @@ struct Material {
     rt_material pod() const { return rt_material{ambient, diffuse, specular, specular_exp, texture, bump, disp}; }
 };
 
-struct Library {  // Common.cuh:131-150 (materials only; textures are a "next" row)
+// Texture (Common.cuh:61-91): an RGBA8 mip chain on the host; GenerateLODs = the box filter of FileIO.cpp:121-150.
+// The reference decodes images with the vendored stb_image; this build reads binary PPM (P6) only.
+constexpr int NUM_LODS = RT_NUM_LODS;   // Common.cuh:17
+struct Texture {
+    std::string name;
+    std::vector<uint32_t> mips[NUM_LODS];   // texel = r | g << 8 | b << 16 | a << 24, row 0 first
+    int size_x[NUM_LODS] = {0}, size_y[NUM_LODS] = {0};
+    uint32_t max_lod = 0;
+    uint32_t ReadTexel(int x, int y, int lod) const;          // coordinates clamped (FileIO.cpp:109-114)
+    void GenerateLODs();
+};
+
+struct Library {  // Common.cuh:131-150
     std::vector<Material> materials;
+    std::vector<Texture> textures;
     std::map<std::string, uint32_t> name_to_mat;
+    std::map<std::string, uint32_t> name_to_tex;
+    int32_t AddTexture(const std::string& filename);           // FileIO.cpp:166-184; -1 when the file cannot be decoded
     void AddMaterial(const std::string& name) { name_to_mat[name] = (uint32_t)materials.size(); materials.emplace_back(name); }
     int32_t GetMaterialId(const std::string& name) const
     {

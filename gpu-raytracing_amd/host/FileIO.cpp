@@ -1,5 +1,6 @@
 #include "FileIO.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -70,7 +71,82 @@ vec3 SetupLight(const std::string& obj_name, const AABB& aabb)  // FileIO.cpp:74
     return result;
 }
 
+// binary PPM (P6, maxval 255) -> RGBA8 with alpha 255
+bool LoadPPM(const std::string& filename, Texture& tex)
+{
+    std::ifstream is(filename, std::ios::binary);
+    if (!is.good()) return false;
+    std::string magic;
+    is >> magic;
+    if (magic != "P6") return false;
+    int vals[3], got = 0;
+    while (got < 3 && is.good()) {
+        is >> std::ws;
+        if (is.peek() == '#') { std::string c; std::getline(is, c); continue; }
+        is >> vals[got++];
+    }
+    if (got < 3 || vals[0] <= 0 || vals[1] <= 0 || vals[2] != 255) return false;
+    is.get();   // the single whitespace after maxval
+    std::vector<unsigned char> rgb((size_t)vals[0] * vals[1] * 3);
+    is.read(reinterpret_cast<char*>(rgb.data()), (std::streamsize)rgb.size());
+    if ((size_t)is.gcount() != rgb.size()) return false;
+    tex.size_x[0] = vals[0];
+    tex.size_y[0] = vals[1];
+    tex.mips[0].resize((size_t)vals[0] * vals[1]);
+    for (size_t i = 0; i < tex.mips[0].size(); i++)
+        tex.mips[0][i] = rgb[3 * i] | (rgb[3 * i + 1] << 8) | (rgb[3 * i + 2] << 16) | 0xFF000000u;
+    return true;
+}
+
 }  // namespace
+
+uint32_t Texture::ReadTexel(int x, int y, int lod) const
+{
+    x = std::max(0, std::min(x, size_x[lod] - 1));
+    y = std::max(0, std::min(y, size_y[lod] - 1));
+    return mips[lod][(size_t)y * size_x[lod] + x];
+}
+
+void Texture::GenerateLODs()   // FileIO.cpp:121-150
+{
+    uint32_t lod = 0;
+    while ((size_x[lod] > 1 || size_y[lod] > 1) && lod + 1 < (uint32_t)NUM_LODS) {
+        size_x[lod + 1] = (size_x[lod] + 1) / 2;
+        size_y[lod + 1] = (size_y[lod] + 1) / 2;
+        mips[lod + 1].resize((size_t)size_x[lod + 1] * size_y[lod + 1]);
+        for (int j = 0; j < size_y[lod + 1]; j++)
+            for (int i = 0; i < size_x[lod + 1]; i++) {
+                const uint32_t t[4] = {ReadTexel(i * 2, j * 2, lod), ReadTexel(i * 2 + 1, j * 2, lod),
+                                       ReadTexel(i * 2, j * 2 + 1, lod), ReadTexel(i * 2 + 1, j * 2 + 1, lod)};
+                uint32_t out = 0;
+                for (int c = 0; c < 4; c++) {
+                    const float sum = (((float)((t[0] >> (8 * c)) & 255u) + (float)((t[1] >> (8 * c)) & 255u)) +
+                                       (float)((t[2] >> (8 * c)) & 255u)) + (float)((t[3] >> (8 * c)) & 255u);
+                    out |= ((uint32_t)(sum * 0.25f) & 255u) << (8 * c);
+                }
+                mips[lod + 1][(size_t)j * size_x[lod + 1] + i] = out;
+            }
+        lod++;
+    }
+    max_lod = lod;
+}
+
+int32_t Library::AddTexture(const std::string& filename)
+{
+    auto it = name_to_tex.find(filename);
+    if (it != name_to_tex.end()) return (int32_t)it->second;
+    printf("Loading %s\n", filename.c_str());
+    Texture tex;
+    tex.name = filename;
+    if (!LoadPPM(filename, tex)) {
+        fprintf(stderr, "warning: %s is not a binary PPM (the only texture format this build decodes); material keeps no texture\n", filename.c_str());
+        return -1;
+    }
+    tex.GenerateLODs();
+    name_to_tex[filename] = (uint32_t)textures.size();
+    textures.push_back(std::move(tex));
+    return (int32_t)textures.size() - 1;
+}
 
 Library LoadMTLFromFile(const std::string& filename)  // FileIO.cpp:222-287
 {
@@ -93,10 +169,13 @@ Library LoadMTLFromFile(const std::string& filename)  // FileIO.cpp:222-287
             library.materials.back().specular_exp = ToFloat(t, 1);
         } else if (t[0] == "map_Kd" && t.size() > 1) {
             library.materials.back().texture_file = JoinPath(BaseDirectory(filename), t[1]);
+            library.materials.back().texture = library.AddTexture(library.materials.back().texture_file);
         } else if (t[0] == "bump" && t.size() > 1) {
             library.materials.back().bump_file = JoinPath(BaseDirectory(filename), t[1]);
+            library.materials.back().bump = library.AddTexture(library.materials.back().bump_file);
         } else if (t[0] == "map_Disp" && t.size() > 1) {
             library.materials.back().disp_file = JoinPath(BaseDirectory(filename), t[1]);
+            library.materials.back().disp = library.AddTexture(library.materials.back().disp_file);
         }
     }
     return library;

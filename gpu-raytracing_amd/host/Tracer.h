@@ -1,6 +1,7 @@
 // Tracer.h -- the reference's Trace() (main.cu:125-192) / TraceRays (Tracer.cuh:21-23) over the C ABI.
 #pragma once
 #include <cstdint>
+#include <vector>
 
 #include "Arguments.h"
 #include "Common.h"
@@ -8,8 +9,20 @@
 struct DeviceSceneView {             // the fields of DeviceScene (Common.cuh:342-351) Trace() fills at main.cu:159-167
     const Attributes* attributes = nullptr;   // device
     const rt_material* materials = nullptr;   // device
-    uint32_t num_attributes = 0, num_materials = 0;
+    const rt_texture* textures = nullptr;     // device table, see DeviceTextureTable
+    uint32_t num_attributes = 0, num_materials = 0, num_textures = 0;
     vec3 light{0, 0, 0};
+};
+
+// The texture part of Scene::CopyToDevice (main.cu:100-113): every mip level of every Library texture in device
+// memory plus the rt_texture table that points at them.
+struct DeviceTextureTable {
+    rt_texture* table = nullptr;              // device
+    uint32_t count = 0;
+    void Upload(const Library& library);
+    void Free();
+private:
+    std::vector<void*> allocations_;
 };
 
 // One frame: rows [y0, y1) of a dims_x x dims_y RGBA8 frame (linear device buffer, row 0 first -- the contents of

@@ -1,7 +1,7 @@
 // main.cpp -- headless counterpart of the reference's main.cu: what Display() does at frame 0 (main.cu:215-265)
 // plus one Trace() (main.cu:125-192), with the frame written as a PPM instead of shown in a GL window.
 //
-//   rt_cli <file.obj> [--type bottom-up|hybrid] [--pairs] [--splits] [--render depth|boxtests|tritests|material|diffuse]
+//   rt_cli <file.obj> [--type bottom-up|hybrid] [--pairs] [--splits] [--render depth|boxtests|tritests|material|lods|diffuse|texture|texturelit|shadows]
 //          [--width W] [--height H] [--spp N] [--yaw Y --pitch P --pos X Y Z] [--out frame.ppm] [--frames K]
 #include <chrono>
 #include <cstdio>
@@ -25,13 +25,17 @@ static RenderType ParseRender(const std::string& s)
     if (s == "tritests") return kTriangleTests;
     if (s == "material") return kMaterialId;
     if (s == "diffuse") return kDiffuse;
+    if (s == "lods") return kLODs;
+    if (s == "texture") return kTexture;
+    if (s == "texturelit") return kTextureLit;
+    if (s == "shadows") return kTextureLitShadows;
     return kDepth;
 }
 
 int main(int argc, char** argv)
 {
     if (argc < 2) {
-        fprintf(stderr, "usage: %s <file.obj> [--type bottom-up|hybrid] [--render depth|boxtests|tritests|material|diffuse] "
+        fprintf(stderr, "usage: %s <file.obj> [--type bottom-up|hybrid] [--render depth|boxtests|tritests|material|lods|diffuse|texture|texturelit|shadows] "
                         "[--width W] [--height H] [--spp N] [--yaw Y] [--pitch P] [--pos X Y Z] [--out f.ppm] [--frames K]\n", argv[0]);
         return 2;
     }
@@ -124,6 +128,10 @@ int main(int argc, char** argv)
     view.num_attributes = n;
     view.num_materials = (uint32_t)mats.size();
     view.light = scene.light;
+    DeviceTextureTable textures;
+    textures.Upload(scene.library);
+    view.textures = textures.table;
+    view.num_textures = textures.count;
 
     MemoryBuffer<uint8_t> frame((size_t)width * height * 4);
     MemoryBuffer<uint64_t> num_tests(4);
@@ -154,5 +162,6 @@ int main(int argc, char** argv)
     (void)hipFree(in.triangles_in); (void)hipFree(in.triangles_out); (void)hipFree(in.scratch); (void)hipFree(in.nodes_out);
     if (d_attr) (void)hipFree(d_attr);
     if (d_mat) (void)hipFree(d_mat);
+    textures.Free();
     return bad ? 1 : 0;
 }

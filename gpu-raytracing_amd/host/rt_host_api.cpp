@@ -34,6 +34,30 @@ const void* rth_materials(void* h) { return static_cast<HostScene*>(h)->mats.dat
 void rth_scene_aabb(void* h, float out[6]) { memcpy(out, &static_cast<HostScene*>(h)->scene.aabb, 24); }
 void rth_light(void* h, float out[3]) { memcpy(out, &static_cast<HostScene*>(h)->scene.light, 12); }
 
+uint32_t rth_num_textures(void* h) { return (uint32_t) static_cast<HostScene*>(h)->scene.library.textures.size(); }
+uint32_t rth_texture_max_lod(void* h, uint32_t t) { return static_cast<HostScene*>(h)->scene.library.textures[t].max_lod; }
+void rth_texture_size(void* h, uint32_t t, uint32_t lod, int out[2])
+{
+    const Texture& x = static_cast<HostScene*>(h)->scene.library.textures[t];
+    out[0] = x.size_x[lod]; out[1] = x.size_y[lod];
+}
+const void* rth_texture_mip(void* h, uint32_t t, uint32_t lod) { return static_cast<HostScene*>(h)->scene.library.textures[t].mips[lod].data(); }
+
+// Texture::GenerateLODs on a caller-supplied level 0; out_mips[l] (l >= 1) must hold size_x[l] * size_y[l] texels.
+// Returns max_lod and fills the size tables (call with out_mips == nullptr first to learn the sizes).
+uint32_t rth_generate_lods(const uint32_t* mip0, int sx, int sy, int* size_x, int* size_y, uint32_t** out_mips)
+{
+    Texture t;
+    t.size_x[0] = sx; t.size_y[0] = sy;
+    t.mips[0].assign(mip0, mip0 + (size_t)sx * sy);
+    t.GenerateLODs();
+    for (uint32_t l = 0; l <= t.max_lod; l++) {
+        size_x[l] = t.size_x[l]; size_y[l] = t.size_y[l];
+        if (out_mips && l >= 1) memcpy(out_mips[l], t.mips[l].data(), t.mips[l].size() * 4);
+    }
+    return t.max_lod;
+}
+
 void rth_initialise_camera(rt_camera* cam, const float aabb[6])
 {
     AABB b;

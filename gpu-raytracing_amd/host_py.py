@@ -24,12 +24,17 @@ def lib():
         L.rth_load_obj.restype = vp
         L.rth_load_obj.argtypes = [ctypes.c_char_p]
         L.rth_free.argtypes = [vp]
-        for f in ("rth_num_triangles", "rth_num_materials"):
+        for f in ("rth_num_triangles", "rth_num_materials", "rth_num_textures"):
             getattr(L, f).restype = u32
             getattr(L, f).argtypes = [vp]
         for f in ("rth_triangles", "rth_attributes", "rth_materials"):
             getattr(L, f).restype = vp
             getattr(L, f).argtypes = [vp]
+        L.rth_texture_max_lod.restype = u32
+        L.rth_texture_max_lod.argtypes = [vp, u32]
+        L.rth_texture_size.argtypes = [vp, u32, u32, vp]
+        L.rth_texture_mip.restype = vp
+        L.rth_texture_mip.argtypes = [vp, u32, u32]
         L.rth_scene_aabb.argtypes = [vp, vp]
         L.rth_light.argtypes = [vp, vp]
         L.rth_initialise_camera.argtypes = [vp, vp]
@@ -58,9 +63,17 @@ def LoadOBJFromFile(path: str) -> dict:
         aabb, light = np.zeros(6, np.float32), np.zeros(3, np.float32)
         L.rth_scene_aabb(h, aabb.ctypes.data_as(ctypes.c_void_p))
         L.rth_light(h, light.ctypes.data_as(ctypes.c_void_p))
+        textures = []                                        # Library::textures: one mip chain per texture
+        for t in range(L.rth_num_textures(h)):
+            chain = []
+            for l in range(L.rth_texture_max_lod(h, t) + 1):
+                sz = np.zeros(2, np.int32)
+                L.rth_texture_size(h, t, l, sz.ctypes.data_as(ctypes.c_void_p))
+                chain.append(_copy(L.rth_texture_mip(h, t, l), np.uint32, int(sz[0]) * int(sz[1])).reshape(int(sz[1]), int(sz[0])))
+            textures.append(chain)
         return dict(triangles=_copy(L.rth_triangles(h), np.float32, n * 9).reshape(n, 9),
                     attributes=_copy(L.rth_attributes(h), _pkg.ATTRIBUTES, n),
-                    materials=_copy(L.rth_materials(h), _pkg.MATERIAL, m), aabb=aabb, light=light)
+                    materials=_copy(L.rth_materials(h), _pkg.MATERIAL, m), aabb=aabb, light=light, textures=textures)
     finally:
         L.rth_free(h)
 

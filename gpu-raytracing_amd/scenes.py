@@ -143,3 +143,40 @@ def default_materials(k: int = 3) -> np.ndarray:
         m[i]["specular_exp"] = np.float32(10.0 + 7 * i)
         m[i]["texture"] = m[i]["bump"] = m[i]["disp"] = -1
     return m
+
+
+def planar_uv_attributes(triangles: np.ndarray, material_ids=None, uv_scale: float = 0.25, axes=(0, 2)) -> np.ndarray:
+    """flat_attributes plus a planar texture mapping uv = position[axes] * uv_scale per corner (what an OBJ with
+    vt records would carry, FileIO.cpp:404-413)."""
+    at = flat_attributes(triangles, material_ids)
+    t = triangles.reshape(-1, 3, 3).astype(np.float32)
+    at["uv"][:, :, 0] = t[:, :, axes[0]] * np.float32(uv_scale)
+    at["uv"][:, :, 1] = t[:, :, axes[1]] * np.float32(uv_scale)
+    return at
+
+
+def procedural_texture(sx: int, sy: int, seed: int = 1, kind: str = "checker") -> np.ndarray:
+    """[sy, sx] uint32 RGBA8 texels (r | g<<8 | b<<16 | a<<24).  kinds: checker (colour blocks + hash noise),
+    noise (hash per texel, used as bump / height map), normal (unit-ish normals around +z, used as a normal map)."""
+    x = np.arange(sx, dtype=np.uint32)[None, :]
+    y = np.arange(sy, dtype=np.uint32)[:, None]
+    with np.errstate(over="ignore"):
+        hsh = pcg_hash(x + np.uint32(0x9E3779B9) * y + np.uint32(seed * 0x01000193))
+    if kind == "checker":
+        c = (((x // 4) + (y // 4)) & 1).astype(np.uint32)
+        r = np.where(c == 1, 220, 40).astype(np.uint32) + (hsh & np.uint32(31))
+        g = np.where(c == 1, 60, 200).astype(np.uint32) + ((hsh >> np.uint32(5)) & np.uint32(31))
+        b = (x * np.uint32(255) // np.uint32(max(sx - 1, 1)) + np.zeros_like(y)).astype(np.uint32)
+        a = np.full((sy, sx), 255, np.uint32) - ((hsh >> np.uint32(10)) & np.uint32(63))
+    elif kind == "noise":
+        r = g = b = (hsh >> np.uint32(12)) & np.uint32(255)
+        a = np.full((sy, sx), 255, np.uint32)
+    elif kind == "normal":
+        r = np.uint32(96) + ((hsh >> np.uint32(3)) & np.uint32(63))
+        g = np.uint32(96) + ((hsh >> np.uint32(11)) & np.uint32(63))
+        b = np.uint32(200) + ((hsh >> np.uint32(19)) & np.uint32(31))
+        a = np.full((sy, sx), 255, np.uint32)
+    else:
+        raise ValueError(kind)
+    r, g, b, a = (np.broadcast_to(v, (sy, sx)).astype(np.uint32) for v in (r, g, b, a))
+    return (r | (g << np.uint32(8)) | (b << np.uint32(16)) | (a << np.uint32(24))).astype(np.uint32)

@@ -62,6 +62,15 @@ typedef struct rt_material {
     int32_t texture, bump, disp;
 } rt_material;
 
+/* POD mirror of the device-read fields of Texture (Common.cuh:61-91): an RGBA8 mip chain.  mips[l] is a DEVICE pointer to
+ * size_x[l] * size_y[l] texels (row 0 first), levels 0..max_lod as Texture::GenerateLODs makes them (FileIO.cpp:121-150). */
+#define RT_NUM_LODS 13
+typedef struct rt_texture {
+    const uint32_t* mips[RT_NUM_LODS];
+    int32_t size_x[RT_NUM_LODS], size_y[RT_NUM_LODS];
+    uint32_t max_lod, pad;
+} rt_texture;
+
 typedef enum rt_child_type { RT_CHILD_NONE = 0, RT_CHILD_BOX = 1, RT_CHILD_TRI = 2 } rt_child_type; /* Common.cuh:35-41 */
 
 /* Arguments.h:8-26 */
@@ -87,11 +96,12 @@ typedef struct rt_build_input {
 /* Common.cuh:335-340 DeviceAccelerationStructure */
 typedef struct rt_accel { const rt_triangle_pair* triangles; const rt_node* nodes; uint32_t root; uint32_t count; } rt_accel;
 
-/* Common.cuh:342-351 DeviceScene (textures: "next" scope, must be NULL/0 for now) */
+/* Common.cuh:342-351 DeviceScene.  textures: device array indexed by rt_material.texture / .bump / .disp; only the
+ * textured render types (kLODs, kTexture, kTextureLit, kTextureLitShadows) read it. */
 typedef struct rt_scene {
     const rt_attributes* attributes;
     const rt_material*   materials;
-    const void*          textures;
+    const rt_texture*    textures;
     const rt_camera*     camera;        /* device pointer, as in the reference (main.cu:151,161) */
     float                light[3];
     uint32_t             num_attributes, num_materials, num_textures;
@@ -100,7 +110,7 @@ typedef struct rt_scene {
 enum {
     RT_OK = 0,
     RT_ERR_INVALID_ARGUMENT = -1,
-    RT_ERR_UNSUPPORTED = -2,       /* splits / SAH builder / textured render types: SURVEY 8(f) "next" rows */
+    RT_ERR_UNSUPPORTED = -2,       /* splits / SAH builder: SURVEY 8(f) "next" rows */
     RT_ERR_TOO_LARGE = -3,         /* n exceeds the 29-bit child index of Node (Common.cuh:152-159) */
     RT_ERR_HIP_BASE = -1000        /* -(hipError_t) + RT_ERR_HIP_BASE */
 };

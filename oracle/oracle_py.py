@@ -137,9 +137,64 @@ def verify_hierarchy(nodes: np.ndarray, root: int, count: int) -> int:
     return int(lib().ora_verify_hierarchy(_p(np.ascontiguousarray(nodes)), root, count))
 
 
+NUM_LODS = 13
+
+
+class _Texture(ctypes.Structure):  # ora_texture
+    _fields_ = [("mips", ctypes.c_void_p * NUM_LODS), ("size_x", ctypes.c_int32 * NUM_LODS),
+                ("size_y", ctypes.c_int32 * NUM_LODS), ("max_lod", ctypes.c_uint32), ("pad", ctypes.c_uint32)]
+
+
+def generate_lods(mip0: np.ndarray) -> list:
+    """Texture::GenerateLODs: mip0 is [sy, sx] uint32 (r | g<<8 | b<<16 | a<<24); returns the list of levels."""
+    L = lib()
+    L.ora_lod_sizes.restype = ctypes.c_uint32
+    L.ora_lod_sizes.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    L.ora_generate_lod.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
+    mip0 = np.ascontiguousarray(mip0, np.uint32)
+    sx, sy = np.zeros(NUM_LODS, np.int32), np.zeros(NUM_LODS, np.int32)
+    max_lod = L.ora_lod_sizes(mip0.shape[1], mip0.shape[0], _p(sx), _p(sy))
+    mips = [mip0]
+    for l in range(1, max_lod + 1):
+        dst = np.zeros((sy[l], sx[l]), np.uint32)
+        L.ora_generate_lod(_p(mips[-1]), int(sx[l - 1]), int(sy[l - 1]), _p(dst))
+        mips.append(dst)
+    return mips
+
+
+def _texture_table(textures):
+    """textures: list of mip chains (each a list of [sy, sx] uint32 arrays).  Returns (ctypes array, keepalive)."""
+    arr = (_Texture * len(textures))()
+    keep = []
+    for t, chain in enumerate(textures):
+        assert 1 <= len(chain) <= NUM_LODS
+        for l, m in enumerate(chain):
+            m = np.ascontiguousarray(m, np.uint32)
+            keep.append(m)
+            arr[t].mips[l] = m.ctypes.data
+            arr[t].size_x[l], arr[t].size_y[l] = m.shape[1], m.shape[0]
+        arr[t].max_lod = len(chain) - 1
+    return arr, keep
+
+
 def trace(leaves, nodes, root, count, camera, w, h, *, render_type=0, attributes=None, materials=None, light=(0, 0, 0),
-          rows=None, spp=1):
-    """TraceRays on the CPU.  Returns (rgba8 [h, w, 4] uint8, counters [box, tri, max_stack])."""
+          rows=None, spp=1, textures=None):
+    """TraceRays on the CPU.  Returns (rgba8 [h, w, 4] uint8, counters [box, tri, max_stack]).
+    textures: list of mip chains (see generate_lods) indexed by Material.texture / .bump / .disp."""
+    L = lib()
+    L.ora_set_textures.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
+    if textures:
+        table, _keep = _texture_table(textures)
+        L.ora_set_textures(ctypes.cast(table, ctypes.c_void_p), len(textures))
+    else:
+        L.ora_set_textures(None, 0)
+    try:
+        return _trace(leaves, nodes, root, count, camera, w, h, render_type, attributes, materials, light, rows, spp)
+    finally:
+        L.ora_set_textures(None, 0)
+
+
+def _trace(leaves, nodes, root, count, camera, w, h, render_type, attributes, materials, light, rows, spp):
     rgba = np.zeros((h, w, 4), np.uint8)
     counters = np.zeros(3, np.uint64)
     y0, y1 = (0, h) if rows is None else rows

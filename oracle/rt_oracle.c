@@ -862,11 +862,165 @@ static ora_f3 hsv_to_rgb255(float h, float s, float v)
     return f3((rgb.x + m) * 255, (rgb.y + m) * 255, (rgb.z + m) * 255);
 }
 
-/* Tracer.cu:376-469 AmbientShader with use_textures = use_shadows = use_bump = false (kDiffuse, :536-541).
- * `max(dot, 0.0)` and pow() are evaluated in double on the device (float/double overloads), the product
- * `1.0f * pow(...)` is narrowed to float by operator*(float, float3) -- restated literally. */
-static ora_f3 ambient_shader255(const ray_t* ray, const ray_result_t* rr, const ora_material* mat,
-                                const ora_attributes* at, const float light[3])
+/* float -> unsigned char as the device does it (cvt.rzi.u8.f32: NaN -> 0, out of range saturates); a plain C cast is
+ * undefined outside [0, 256) and bilinear weights at a texture border do leave that range */
+static inline uint8_t sat_u8(float v) { return !(v > 0.0f) ? 0 : (v >= 255.0f ? 255 : (uint8_t)v); }
+
+/* ================================================================== textures (Tracer.cu:84-254) */
+static const ora_texture* g_textures = 0;
+static uint32_t g_num_textures = 0;
+void ora_set_textures(const ora_texture* t, uint32_t n) { g_textures = t; g_num_textures = n; }
+
+/* Texture::GenerateLODs (FileIO.cpp:121-150): sizes halve rounding up until 1x1; each texel = trunc(0.25 * sum of the
+ * 2x2 source texels, coordinates clamped (ReadTexel :109-114)) */
+uint32_t ora_lod_sizes(int32_t sx0, int32_t sy0, int32_t* sx, int32_t* sy)
+{
+    uint32_t lod = 0;
+    sx[0] = sx0; sy[0] = sy0;
+    while ((sx[lod] > 1 || sy[lod] > 1) && lod + 1 < ORA_NUM_LODS) {
+        sx[lod + 1] = (sx[lod] + 1) / 2;
+        sy[lod + 1] = (sy[lod] + 1) / 2;
+        lod++;
+    }
+    return lod;
+}
+void ora_generate_lod(const uint32_t* src, int32_t sx, int32_t sy, uint32_t* dst)
+{
+    const int32_t dx = (sx + 1) / 2, dy = (sy + 1) / 2;
+    for (int32_t j = 0; j < dy; j++)
+        for (int32_t i = 0; i < dx; i++) {
+            float acc[4] = {0, 0, 0, 0};
+            for (int k = 0; k < 4; k++) {
+                int32_t x = i * 2 + (k & 1), y = j * 2 + (k >> 1);
+                if (x > sx - 1) x = sx - 1;
+                if (y > sy - 1) y = sy - 1;
+                const uint8_t* t = (const uint8_t*)&src[(size_t)y * sx + x];
+                for (int c = 0; c < 4; c++) acc[c] = k == 0 ? (float)t[c] : acc[c] + (float)t[c];
+            }
+            uint8_t* o = (uint8_t*)&dst[(size_t)j * dx + i];
+            for (int c = 0; c < 4; c++) o[c] = sat_u8(acc[c] * 0.25f);
+        }
+}
+
+typedef struct { float x, y; } f2_t;
+static inline float fracf1(float v) { return v - floorf(v); }                                  /* helper_math.h:1367 */
+/* Sample(Texture&, int2, lod) (:103-108) -> float4 of the texel bytes */
+static inline void tex_fetch(const ora_texture* t, int x, int y, int lod, float out[4])
+{
+    const int sx = t->size_x[lod], sy = t->size_y[lod];
+    x = x > sx - 1 ? sx - 1 : x; x = x < 0 ? 0 : x;       /* clamp(xy, 0, size-1) = max(0, min(xy, size-1)) */
+    y = y > sy - 1 ? sy - 1 : y; y = y < 0 ? 0 : y;
+    const uint8_t* p = (const uint8_t*)&t->mips[lod][(size_t)y * sx + x];
+    out[0] = p[0]; out[1] = p[1]; out[2] = p[2]; out[3] = p[3];
+}
+/* BilinearSample (:122-140) */
+static void bilinear_sample(const ora_texture* t, f2_t uv, int lod, uint8_t out[4])
+{
+    float cx = fracf1(uv.x) * (float)t->size_x[lod] - 0.5f;
+    float cy = fracf1(uv.y) * (float)t->size_y[lod] - 0.5f;
+    cy = (float)t->size_y[lod] - cy;
+    const int ix = (int)cx, iy = (int)cy;
+    const float dx = cx - (float)ix, dy = cy - (float)iy;
+    const float w0 = (1.0f - dx) * dy, w1 = dx * dy, w2 = (1.0f - dx) * (1.0f - dy), w3 = dx * (1.0f - dy);
+    float s0[4], s1[4], s2[4], s3[4];
+    tex_fetch(t, ix, iy, lod, s0);
+    tex_fetch(t, ix + 1, iy, lod, s1);
+    tex_fetch(t, ix, iy - 1, lod, s2);
+    tex_fetch(t, ix + 1, iy - 1, lod, s3);
+    for (int c = 0; c < 4; c++) out[c] = sat_u8(((s0[c] * w0 + s1[c] * w1) + s2[c] * w2) + s3[c] * w3);
+}
+/* TrilinearSample (:142-155) */
+static void trilinear_sample(const ora_texture* t, f2_t uv, float lod, uint8_t out[4])
+{
+    uint32_t min_lod = (uint32_t)floorf(lod), max_lod = min_lod + 1;
+    min_lod = min_lod > t->max_lod ? t->max_lod : min_lod;
+    max_lod = max_lod > t->max_lod ? t->max_lod : max_lod;
+    uint8_t a[4], b[4];
+    bilinear_sample(t, uv, (int)min_lod, a);
+    bilinear_sample(t, uv, (int)max_lod, b);
+    const float frac = fracf1(lod);
+    for (int c = 0; c < 4; c++) out[c] = sat_u8((float)a[c] * (1.0f - frac) + (float)b[c] * frac);
+}
+static inline f2_t interp_uv(const ora_attributes* at, float bu, float bv)               /* InterpolateUVs (:43-48) */
+{
+    const float w0 = 1 - bu - bv;
+    f2_t r;
+    r.x = (at->uv[0][0] * w0 + at->uv[1][0] * bu) + at->uv[2][0] * bv;
+    r.y = (at->uv[0][1] * w0 + at->uv[1][1] * bu) + at->uv[2][1] * bv;
+    return r;
+}
+/* RayTriangleGradients (:202-235): barycentrics of the hit with the ray moved by one pixel in x and in y */
+static void ray_triangle_gradients(const ora_f3 v[3], const ray_t* ray, float spread, float out[4])
+{
+    ora_f3 edge1 = sub3(v[1], v[0]), edge2 = sub3(v[2], v[0]);
+    ora_f3 s = sub3(ray->origin, v[0]);
+    ora_f3 q = cross3(s, edge1);
+    ora_f3 x = scale3(scale3(normalize3(cross3(ray->direction, f3(0, 1, 0))), ray->tmax), spread);
+    ora_f3 y = scale3(scale3(normalize3(cross3(ray->direction, x)), ray->tmax), spread);
+    ora_f3 hit_point = add3(ray->origin, scale3(ray->direction, ray->tmax));
+    ora_f3 dirx = normalize3(sub3(add3(hit_point, x), ray->origin));
+    ora_f3 diry = normalize3(sub3(add3(hit_point, y), ray->origin));
+    ora_f3 h0 = cross3(dirx, edge2);
+    float a0 = dot3(edge1, h0), f0 = 1.0f / a0;
+    out[0] = f0 * dot3(s, h0);
+    out[1] = f0 * dot3(dirx, q);
+    ora_f3 h1 = cross3(diry, edge2);
+    float a1 = dot3(edge1, h1), f1 = 1.0f / a1;
+    out[2] = f1 * dot3(s, h1);
+    out[3] = f1 * dot3(diry, q);
+}
+/* ComputeLOD (:237-254) */
+static float compute_lod(const ray_t* ray, const ray_result_t* rr, float spread, const ora_f3 tri[3],
+                         const ora_attributes* at, const ora_texture* tex)
+{
+    float g[4];
+    ray_triangle_gradients(tri, ray, spread, g);
+    f2_t uvs = interp_uv(at, rr->bu, rr->bv), ux = interp_uv(at, g[0], g[1]), uy = interp_uv(at, g[2], g[3]);
+    const float sx = (float)tex->size_x[0], sy = (float)tex->size_y[0];
+    const float dxx = fabsf(ux.x - uvs.x) * sx, dxy = fabsf(ux.y - uvs.y) * sy;
+    const float dyx = fabsf(uy.x - uvs.x) * sx, dyy = fabsf(uy.y - uvs.y) * sy;
+    const float max_change = fmaxf(sqrtf(dxx * dxx + dxy * dxy), sqrtf(dyx * dyx + dyy * dyy));
+    return clampf(log2f(max_change), 0.0f, (float)tex->max_lod);
+}
+/* TangentMatrix (:84-101): rows of the tangent/bitangent/normal frame */
+static void tangent_matrix(const ora_f3 tri[3], const ora_attributes* at, ora_f3 rows[3])
+{
+    ora_f3 e1 = sub3(tri[1], tri[0]), e2 = sub3(tri[2], tri[0]);
+    const float d1x = at->uv[1][0] - at->uv[0][0], d1y = at->uv[1][1] - at->uv[0][1];
+    const float d2x = at->uv[2][0] - at->uv[0][0], d2y = at->uv[2][1] - at->uv[0][1];
+    const float f = 1.0f / (d1x * d2y - d1y * d2x);
+    ora_f3 normal = normalize3(cross3(e1, e2));
+    ora_f3 tangent = normalize3(scale3(sub3(scale3(e1, d2y), scale3(e2, d1y)), f));
+    ora_f3 bitangent = normalize3(scale3(sub3(scale3(e2, d1x), scale3(e1, d2x)), f));
+    rows[0] = f3(tangent.x, bitangent.x, normal.x);
+    rows[1] = f3(tangent.y, bitangent.y, normal.y);
+    rows[2] = f3(tangent.z, bitangent.z, normal.z);
+}
+/* Bump2Normal (:157-185) */
+static ora_f3 bump2normal(const ora_texture* tex, const ora_f3 tbn[3], f2_t uv, float lod)
+{
+    const float texel_step = powf(2.0f, lod);
+    const float stx = texel_step / (float)tex->size_x[0], sty = texel_step / (float)tex->size_y[0];
+    uint8_t a[4], b[4], c[4];
+    f2_t ua = {uv.x - stx * 0.5f, uv.y - sty * 0.5f}, ub = {uv.x + stx * 0.5f, uv.y + 0.0f}, uc = {uv.x + 0.0f, uv.y + sty * 0.5f};
+    trilinear_sample(tex, ua, lod, a);
+    trilinear_sample(tex, ub, lod, b);
+    trilinear_sample(tex, uc, lod, c);
+    const float gx = (float)b[0] - a[0], gy = (float)c[0] - a[0];
+    const float d = 4.0f;
+    ora_f3 n = normalize3(cross3(f3(1, 0, d * gx / (texel_step * 256.0f)), f3(0, 1, d * gy / (texel_step * 256.0f))));
+    n = f3(dot3(tbn[0], n), dot3(tbn[1], n), dot3(tbn[2], n));
+    return normalize3(n);
+}
+
+/* Tracer.cu:376-469 AmbientShader.  `max(dot, 0.0)` and pow() are evaluated in double on the device (float/double
+ * overloads), the product `1.0f * pow(...)` is narrowed to float by operator*(float, float3) -- restated literally. */
+typedef struct {
+    const ora_triangle_pair* leaves; const ora_node* nodes; uint32_t root, count;
+} accel_t;
+static ora_f3 ambient_shader255(const accel_t* as, const ray_t* ray, const ray_result_t* rr, const ora_material* mat,
+                                const ora_attributes* at, const float light[3], float spread, int use_textures,
+                                int use_shadows, int use_bump)
 {
     ora_f3 light_colour = f3(1.0f, 0.9f, 0.8f);
     ora_f3 light_pos = f3(light[0], light[1], light[2]);
@@ -874,6 +1028,29 @@ static ora_f3 ambient_shader255(const ray_t* ray, const ray_result_t* rr, const 
     /* InterpolateNormals (:50-56) */
     float w0 = 1 - rr->bu - rr->bv;
     ora_f3 normal = add3(add3(scale3(at->normal[0], w0), scale3(at->normal[1], rr->bu)), scale3(at->normal[2], rr->bv));
+    const ora_triangle_pair* pair = &as->leaves[rr->tri_id >> 1];
+    ora_f3 tri[3];
+    if (rr->tri_id & 1) { tri[0] = pair->v2; tri[1] = pair->v1; tri[2] = pair->v3; }
+    else { tri[0] = pair->v0; tri[1] = pair->v1; tri[2] = pair->v2; }
+    if (use_bump && mat->disp != -1) {                    /* displacement map used as a normal map (:388-403) */
+        const ora_texture* disp = &g_textures[mat->disp];
+        f2_t uvs = interp_uv(at, rr->bu, rr->bv);
+        float lod = compute_lod(ray, rr, spread, tri, at, disp);
+        ora_f3 tbn[3];
+        tangent_matrix(tri, at, tbn);
+        uint8_t smp[4];
+        trilinear_sample(disp, uvs, lod, smp);
+        normal = f3(smp[0] / 255.0f, smp[1] / 255.0f, smp[2] / 255.0f);
+        normal = normalize3(f3(normal.x * 2.0f - 1.0f, normal.y * 2.0f - 1.0f, normal.z * 2.0f - 1.0f));
+        normal = normalize3(f3(dot3(tbn[0], normal), dot3(tbn[1], normal), dot3(tbn[2], normal)));
+    } else if (use_bump && mat->bump != -1) {             /* (:405-415) */
+        const ora_texture* bump = &g_textures[mat->bump];
+        f2_t uvs = interp_uv(at, rr->bu, rr->bv);
+        float lod = compute_lod(ray, rr, spread, tri, at, bump);
+        ora_f3 tbn[3];
+        tangent_matrix(tri, at, tbn);
+        normal = bump2normal(bump, tbn, uvs, lod);
+    }
     ora_f3 light_dir = normalize3(sub3(light_pos, hit_pos));
     ora_f3 ambient = scale3(light_colour, 0.2f);
     ora_f3 diffuse = scale3(light_colour, 1.0f * fmaxf(dot3(normal, light_dir), 0.0f));
@@ -884,7 +1061,29 @@ static ora_f3 ambient_shader255(const ray_t* ray, const ray_result_t* rr, const 
     double sp_base = fmax((double)dot3(neg_d, refl), 0.0);
     float sp = (float)(1.0f * pow(sp_base, (double)mat->specular_exp));
     ora_f3 specular = scale3(light_colour, sp);
-    ora_f3 colour = add3(add3(mul3(diffuse, mat->diffuse), mul3(ambient, mat->ambient)), mul3(specular, mat->specular));
+    ora_f3 object_diffuse = mat->diffuse;
+    if (use_textures && mat->texture != -1) {             /* (:432-445): BilinearSample(tex, uv, (int)lod) */
+        const ora_texture* tex = &g_textures[mat->texture];
+        float lod = compute_lod(ray, rr, spread, tri, at, tex);
+        uint8_t smp[4];
+        bilinear_sample(tex, interp_uv(at, rr->bu, rr->bv), (int)lod, smp);
+        object_diffuse = f3((float)smp[0] / 255, (float)smp[1] / 255, (float)smp[2] / 255);
+    }
+    if (use_shadows) {                                    /* (:447-462) */
+        ray_t shadow;
+        ray_result_t sres = {0, 0, 0.f, 0.f};
+        stats_t sstats = {0, 0, 0};
+        shadow.origin = hit_pos;
+        shadow.direction = light_dir;
+        shadow.tmin = 0.001f;
+        ora_f3 to_light = sub3(light_pos, hit_pos);
+        shadow.tmax = sqrtf(dot3(to_light, to_light));
+        if (trace_ray(as->leaves, as->nodes, as->root, as->count, &shadow, &sres, &sstats)) {
+            diffuse = f3(0, 0, 0);
+            specular = f3(0, 0, 0);
+        }
+    }
+    ora_f3 colour = add3(add3(mul3(diffuse, object_diffuse), mul3(ambient, mat->ambient)), mul3(specular, mat->specular));
     colour = f3(clampf(colour.x, 0.0f, 1.0f), clampf(colour.y, 0.0f, 1.0f), clampf(colour.z, 0.0f, 1.0f));
     return f3(colour.x * 255, colour.y * 255, colour.z * 255);
 }
@@ -894,8 +1093,9 @@ static ora_f3 ambient_shader255(const ray_t* ray, const ray_result_t* rr, const 
 static ora_f3 shade_pixel(const ora_triangle_pair* leaves, const ora_node* nodes, uint32_t root, uint32_t count,
                           const ora_attributes* attributes, const ora_material* materials, uint32_t num_materials,
                           const ora_camera* cam, const float light[3], int render_type, uint32_t x, uint32_t y,
-                          uint32_t w, uint32_t h, float ox, float oy, stats_t* stats)
+                          uint32_t w, uint32_t h, float ox, float oy, stats_t* stats, float* alpha)
 {
+    *alpha = 255.0f;
     float cx = (float)x, cy = (float)y;
     float ndcx = 2 * ((cx + ox) / (float)w) - 1;
     float ndcy = 2 * ((cy + oy) / (float)h) - 1;
@@ -929,14 +1129,43 @@ static ora_f3 shade_pixel(const ora_triangle_pair* leaves, const ora_node* nodes
     }
     default: break;
     }
-    if (!hit) return f3(0, 0, 0);
+    /* attributes / material are fetched before the hit test in the reference (:506-509): primitive 0 on a miss */
     int second_tri = rr.tri_id & 1;
     const ora_triangle_pair* pair = &leaves[rr.tri_id >> 1];
     ora_attributes at = rotate_attributes(&attributes[rr.primitive_id], second_tri, pair->rot_x, pair->rot_y);
+    const ora_material* mat = &materials[at.material_id];
+    const accel_t as = {leaves, nodes, root, count};
+    const float spread = 2.0f / w;
+    ora_f3 tri[3];
+    if (second_tri) { tri[0] = pair->v2; tri[1] = pair->v1; tri[2] = pair->v3; }
+    else { tri[0] = pair->v0; tri[1] = pair->v1; tri[2] = pair->v2; }
+    if (render_type == ORA_LODS) {                        /* (:543-556) */
+        if (mat->texture != -1 && hit) {
+            float lod = compute_lod(&ray, &rr, 2.0f / w, tri, &at, &g_textures[mat->texture]);
+            float v = (float)(uint8_t)((int)lod * 20);   /* (unsigned char)(int(lod) * 20): integer wrap, <= 240 for 13 LODs */
+            *alpha = v;
+            return f3(v, v, v);
+        }
+        return f3(255, 0, 255);
+    }
+    if (!hit) return f3(0, 0, 0);
     if (render_type == ORA_MATERIALID)
         return hsv_to_rgb255((float)at.material_id / num_materials, 1.0f, 1.0f);
+    if (render_type == ORA_TEXTURE) {                     /* (:557-578) */
+        if (mat->texture != -1) {
+            const ora_texture* tex = &g_textures[mat->texture];
+            float lod = compute_lod(&ray, &rr, 2.0f / w, tri, &at, tex);
+            uint8_t c[4];
+            trilinear_sample(tex, interp_uv(&at, rr.bu, rr.bv), lod, c);
+            *alpha = c[3];
+            return f3(c[0], c[1], c[2]);
+        }
+        return f3(mat->diffuse.x * 255, mat->diffuse.y * 255, mat->diffuse.z * 255);
+    }
+    if (render_type == ORA_TEXTURE_LIT) return ambient_shader255(&as, &ray, &rr, mat, &at, light, spread, 1, 0, 1);
+    if (render_type == ORA_TEXTURE_LIT_SHADOWS) return ambient_shader255(&as, &ray, &rr, mat, &at, light, spread, 1, 1, 1);
     /* ORA_DIFFUSE */
-    return ambient_shader255(&ray, &rr, &materials[at.material_id], &at, light);
+    return ambient_shader255(&as, &ray, &rr, mat, &at, light, spread, 0, 0, 0);
 }
 
 int ora_trace(const ora_triangle_pair* leaves, const ora_node* nodes, uint32_t root, uint32_t count,
@@ -944,9 +1173,7 @@ int ora_trace(const ora_triangle_pair* leaves, const ora_node* nodes, uint32_t r
               const ora_camera* camera, const float light[3], int render_type, uint8_t* rgba8, uint32_t w,
               uint32_t h, uint32_t y0, uint32_t y1, uint32_t spp, uint64_t* counters)
 {
-    if (!(render_type == ORA_DEPTH || render_type == ORA_BOXTESTS || render_type == ORA_TRITESTS ||
-          render_type == ORA_MATERIALID || render_type == ORA_DIFFUSE))
-        return -1;
+    if (render_type < 0 || render_type > ORA_TEXTURE_LIT_SHADOWS) return -1;
     if (spp < 1) spp = 1;
     uint64_t box = 0, tri = 0;
     uint32_t maxst = 0;
@@ -956,23 +1183,27 @@ int ora_trace(const ora_triangle_pair* leaves, const ora_node* nodes, uint32_t r
         for (uint32_t x = 0; x < w; x++) {
             stats_t st = {0, 0, 0};
             ora_f3 c;
+            float alpha = 255.0f;
             if (spp == 1) {
                 c = shade_pixel(leaves, nodes, root, count, attributes, materials, num_materials, camera, light,
-                                render_type, x, y, w, h, 0.5f, 0.5f, &st);
+                                render_type, x, y, w, h, 0.5f, 0.5f, &st, &alpha);
             } else {
                 ora_f3 acc = f3(0, 0, 0);
+                float aacc = 0.0f;
                 for (uint32_t s = 0; s < spp; s++) {
-                    float ox = ((float)(s % 4) + 0.5f) / 4.0f, oy = ((float)((s / 4) % 4) + 0.5f) / 4.0f;
+                    float ox = ((float)(s % 4) + 0.5f) / 4.0f, oy = ((float)((s / 4) % 4) + 0.5f) / 4.0f, a1;
                     acc = add3(acc, shade_pixel(leaves, nodes, root, count, attributes, materials, num_materials,
-                                                camera, light, render_type, x, y, w, h, ox, oy, &st));
+                                                camera, light, render_type, x, y, w, h, ox, oy, &st, &a1));
+                    aacc += a1;
                 }
                 c = f3(acc.x / (float)spp, acc.y / (float)spp, acc.z / (float)spp);
+                alpha = aacc / (float)spp;
             }
             uint8_t* px = rgba8 + ((size_t)y * w + x) * 4;
-            px[0] = (uint8_t)c.x;
-            px[1] = (uint8_t)c.y;
-            px[2] = (uint8_t)c.z;
-            px[3] = 255;
+            px[0] = sat_u8(c.x);
+            px[1] = sat_u8(c.y);
+            px[2] = sat_u8(c.z);
+            px[3] = sat_u8(alpha);
             box += st.box_tests;
             tri += st.tri_tests;
             if (st.max_stack > maxst) maxst = st.max_stack;

@@ -66,8 +66,18 @@ typedef struct {
     int32_t texture, bump, disp;
 } ora_material;
 
+/* POD mirror of the device-read fields of Texture (Common.cuh:61-91): RGBA8 mip chain, mips[l] has size_x[l] x size_y[l]
+ * texels (row 0 first), levels 0..max_lod (Texture::GenerateLODs, FileIO.cpp:121-150) */
+#define ORA_NUM_LODS 13
+typedef struct {
+    const uint32_t* mips[ORA_NUM_LODS];
+    int32_t size_x[ORA_NUM_LODS], size_y[ORA_NUM_LODS];
+    uint32_t max_lod, pad;
+} ora_texture;
+
 enum { ORA_TYPE_NONE = 0, ORA_TYPE_BOX = 1, ORA_TYPE_TRI = 2 };          /* Common.cuh:35-41 */
-enum { ORA_DEPTH = 0, ORA_BOXTESTS = 1, ORA_TRITESTS = 2, ORA_MATERIALID = 3, ORA_DIFFUSE = 5 }; /* Arguments.h:15-26 */
+enum { ORA_DEPTH = 0, ORA_BOXTESTS = 1, ORA_TRITESTS = 2, ORA_MATERIALID = 3, ORA_LODS = 4, ORA_DIFFUSE = 5,
+       ORA_TEXTURE = 6, ORA_TEXTURE_LIT = 7, ORA_TEXTURE_LIT_SHADOWS = 8 }; /* Arguments.h:15-26 */
 
 void ora_set_threads(int n);
 int  ora_get_threads(void);
@@ -135,6 +145,12 @@ int ora_trace(const ora_triangle_pair* leaves, const ora_node* nodes, uint32_t r
               const ora_camera* camera, const float light[3], int render_type,
               uint8_t* rgba8, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t spp,
               uint64_t* counters);
+/* the textured render types (kLODs, kTexture, kTextureLit, kTextureLitShadows; Tracer.cu:103-254,376-469,543-593) read
+ * this table (indexed by Material.texture / .bump / .disp); set it before ora_trace, NULL to clear */
+void ora_set_textures(const ora_texture* textures, uint32_t num_textures);
+/* Texture::GenerateLODs (FileIO.cpp:121-150): fills mips[1..] (caller-allocated, sizes via ora_lod_sizes) */
+uint32_t ora_lod_sizes(int32_t sx0, int32_t sy0, int32_t* size_x, int32_t* size_y);
+void ora_generate_lod(const uint32_t* src, int32_t sx, int32_t sy, uint32_t* dst);
 
 /* analysis aid: when set, ora_trace adds 1 to p[first slot] for every sibling pair a ray visits */
 void ora_set_visit_counts(uint32_t* p);

@@ -77,3 +77,32 @@ def test_count_and_verify_match_oracle_and_reference(host, ora, scenes):
     bad = b["nodes"].copy()
     bad["min"][77, 2] -= 3.0
     assert host.VerifyHierarchy(bad, 0, 2) == ora.verify_hierarchy(bad, 0, 2) == 1
+
+
+def test_load_textured_obj(host, ora):
+    """map_Kd / bump in the .mtl -> Library::AddTexture -> PPM decode -> GenerateLODs (FileIO.cpp:121-184, 232-258)."""
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiles")
+    s = host.LoadOBJFromFile(os.path.join(gold, "tiles.obj"))
+    assert s["triangles"].shape[0] == 6 * 6 * 2 + 4
+    assert len(s["textures"]) == 2                      # tiles_kd.ppm is shared by both materials
+    m = s["materials"]
+    assert (m["texture"][-2:] == 0).all() and m["bump"][-2] == -1 and m["bump"][-1] == 1 and (m["disp"] == -1).all()
+    kd, bump = s["textures"]
+    assert kd[0].shape == (12, 16) and bump[0].shape == (8, 8)
+    assert [c.shape for c in kd] == [(12, 16), (6, 8), (3, 4), (2, 2), (1, 1)]
+    # texel (0, 0) of tiles_kd.ppm: checker cell 0 -> (50, 90, 200), alpha 255
+    assert kd[0][0, 0] == (50 | 90 << 8 | 200 << 16 | 255 << 24)
+    for chain in (kd, bump):
+        exp = ora.generate_lods(chain[0])
+        assert len(exp) == len(chain)
+        for a, b in zip(chain, exp):
+            assert (a == b).all()
+    # vt records reach the attributes
+    assert s["attributes"]["uv"].max() == pytest.approx(4.5)
+
+
+def test_unreadable_texture_keeps_material_untextured(host, tmp_path):
+    (tmp_path / "a.obj").write_text("mtllib a.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl m\nf 1 2 3\n")
+    (tmp_path / "a.mtl").write_text("newmtl m\nKd 1 0 0\nmap_Kd missing.png\n")
+    s = host.LoadOBJFromFile(str(tmp_path / "a.obj"))
+    assert len(s["textures"]) == 0 and s["materials"]["texture"][-1] == -1
