@@ -171,7 +171,7 @@ const char* rt_error_string(int code)
     switch (code) {
     case RT_OK: return "ok";
     case RT_ERR_INVALID_ARGUMENT: return "invalid argument";
-    case RT_ERR_UNSUPPORTED: return "unsupported option (splits / SAH builder / textured render type)";
+    case RT_ERR_UNSUPPORTED: return "unsupported option (splits / SAH builder)";
     case RT_ERR_TOO_LARGE: return "too many triangles for the 29-bit node index";
     default: break;
     }
