@@ -88,7 +88,13 @@ class _ScratchLayout(ctypes.Structure):
                 ("sorted_indices", ctypes.c_size_t), ("total", ctypes.c_size_t)]
 
 
+class _SahScratchLayout(ctypes.Structure):
+    _fields_ = [("p_aabb", ctypes.c_size_t), ("c_aabb", ctypes.c_size_t), ("status", ctypes.c_size_t),
+                ("num_leaves", ctypes.c_size_t), ("cell_counts", ctypes.c_size_t), ("total", ctypes.c_size_t)]
+
+
 EXPORTS = ["rt_bu_memory_requirements", "rt_nodes_bytes", "rt_run_bottom_up_build", "rt_bu_scratch_layout_get",
+           "rt_sah_memory_requirements", "rt_run_sah_build", "rt_sah_scratch_layout_get",
            "rt_calculate_scene_aabb", "rt_generate_morton_codes", "rt_radix_sort_scratch_bytes",
            "rt_radix_sort_u32_pairs", "rt_trace", "rt_error_string", "rt_version_string"]
 
@@ -113,6 +119,12 @@ def lib() -> ctypes.CDLL:
     L.rt_run_bottom_up_build.argtypes = [ctypes.POINTER(_BuildInput), ctypes.POINTER(_Arguments), i32, vp]
     L.rt_bu_scratch_layout_get.restype = i32
     L.rt_bu_scratch_layout_get.argtypes = [u32, ctypes.POINTER(_ScratchLayout)]
+    L.rt_sah_memory_requirements.restype = ctypes.c_size_t
+    L.rt_sah_memory_requirements.argtypes = [u32]
+    L.rt_run_sah_build.restype = i32
+    L.rt_run_sah_build.argtypes = [ctypes.POINTER(_BuildInput), ctypes.POINTER(_Arguments), vp]
+    L.rt_sah_scratch_layout_get.restype = i32
+    L.rt_sah_scratch_layout_get.argtypes = [u32, ctypes.POINTER(_SahScratchLayout)]
     L.rt_calculate_scene_aabb.restype = i32
     L.rt_calculate_scene_aabb.argtypes = [vp, u32, vp, vp]
     L.rt_generate_morton_codes.restype = i32
@@ -199,14 +211,15 @@ class BuildInput:
     scratch: object
 
     @staticmethod
-    def allocate(triangles: np.ndarray, device="cuda") -> "BuildInput":
-        """What Display() does at frame 0 (main.cu:226-240): allocate the four buffers, upload triangles."""
+    def allocate(triangles: np.ndarray, device="cuda", sah: bool = False) -> "BuildInput":
+        """What Display() does at frame 0 (main.cu:226-240): allocate the four buffers, upload triangles.
+        sah: size the scratch with SahMemoryRequirements instead of BuMemoryRequirements (main.cu:227-234)."""
         tri = np.ascontiguousarray(triangles, dtype=np.float32).reshape(-1, 9)
         n = tri.shape[0]
         return BuildInput(triangles_in=to_device(tri, device) if n else device_bytes(64, device),
                           triangles_out=device_bytes(64 * max(n, 1) + 64, device), num_triangles=n,
                           nodes_out=device_bytes(NodesBytes(n), device),
-                          scratch=device_bytes(BuMemoryRequirements(n), device))
+                          scratch=device_bytes(SahMemoryRequirements(n) if sah else BuMemoryRequirements(n), device))
 
 
 def RunBottomUpBuild(inp: BuildInput, args: Optional[Arguments] = None, hybrid: bool = False, stream=None) -> None:
@@ -217,6 +230,26 @@ def RunBottomUpBuild(inp: BuildInput, args: Optional[Arguments] = None, hybrid: 
     ca = _Arguments(args.build_type, int(args.enable_splits), int(args.enable_pairs), args.render_type)
     _check(lib().rt_run_bottom_up_build(ctypes.byref(ci), ctypes.byref(ca), int(hybrid), _stream_ptr(stream)),
            "rt_run_bottom_up_build")
+
+
+def SahMemoryRequirements(num_triangles: int) -> int:
+    """BuildWrapper.cu:126-130"""
+    return int(lib().rt_sah_memory_requirements(num_triangles))
+
+
+def RunSahBuild(inp: BuildInput, args: Optional[Arguments] = None, stream=None) -> None:
+    """BuildWrapper.cu:140-251.  Trace root = (0, 1).  Synchronises `stream` (data-dependent number of levels)."""
+    args = args or Arguments(build_type=kSAH)
+    ci = _BuildInput(_ptr(inp.triangles_in), _ptr(inp.triangles_out), inp.num_triangles, _ptr(inp.nodes_out),
+                     _ptr(inp.scratch))
+    ca = _Arguments(args.build_type, int(args.enable_splits), int(args.enable_pairs), args.render_type)
+    _check(lib().rt_run_sah_build(ctypes.byref(ci), ctypes.byref(ca), _stream_ptr(stream)), "rt_run_sah_build")
+
+
+def sah_scratch_layout(num_triangles: int) -> _SahScratchLayout:
+    out = _SahScratchLayout()
+    _check(lib().rt_sah_scratch_layout_get(num_triangles, ctypes.byref(out)), "rt_sah_scratch_layout_get")
+    return out
 
 
 def scratch_layout(num_triangles: int) -> _ScratchLayout:

@@ -243,6 +243,16 @@ hipError_t launch_morton_pairs(uint32_t* codes, uint32_t* values, const rt_trian
     return hipGetLastError();
 }
 
+hipError_t launch_pair_slots(const rt_triangle* tris, uint32_t n, uint8_t* flags, uint32_t* block_sums,
+                             uint32_t* num_leaves, hipStream_t st)
+{
+    const uint32_t cand = (n + 1) / 2;
+    const uint32_t blocks = (cand + kPairThreads - 1) / kPairThreads;
+    if (n) pair_flags_kernel<<<blocks, kPairThreads, 0, st>>>(reinterpret_cast<const float*>(tris), n, flags, block_sums);
+    pair_scan_kernel<<<1, 1024, 0, st>>>(block_sums, n ? blocks : 0, num_leaves);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------
 hipError_t launch_reset_aabb(int* aabb, hipStream_t st)
 {

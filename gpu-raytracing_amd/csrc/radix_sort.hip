@@ -204,4 +204,22 @@ hipError_t launch_radix_sort(uint32_t* keys, uint32_t* vals, uint32_t* tmp_keys,
     return hipGetLastError();
 }
 
+hipError_t launch_radix_pass(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
+                             uint32_t n, uint32_t shift, void* sort_scratch, hipStream_t st, const uint32_t* n_dev,
+                             uint32_t** digit_total)
+{
+    const SortScratch L = sort_scratch_layout(n);
+    char* base = static_cast<char*>(sort_scratch);
+    uint32_t* dt = reinterpret_cast<uint32_t*>(base + L.digit_total);
+    if (digit_total) *digit_total = dt;
+    if (n == 0) return hipSuccess;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(base + L.hist);
+    uint32_t* offs = reinterpret_cast<uint32_t*>(base + L.offs);
+    const uint32_t tiles = sort_num_tiles(n);
+    sort_upsweep_kernel<<<tiles, kSortThreads, 0, st>>>(keys_in, n, shift, tiles, hist, n_dev);
+    sort_scan_kernel<<<kRadix, 256, 0, st>>>(hist, tiles, offs, dt);
+    sort_downsweep_kernel<<<tiles, kSortThreads, 0, st>>>(keys_in, vals_in, keys_out, vals_out, n, shift, tiles, offs, dt, n_dev);
+    return hipGetLastError();
+}
+
 }  // namespace rt

@@ -1,7 +1,8 @@
 // rt_abi.hip -- the extern "C" entry points declared in include/rt_abi.h.
 // Host orchestration only: scratch carving and kernel order (the role of BuildWrapper.cu:68-136,
-// 253-362 and main.cu:125-192 in the reference).  No allocation, no synchronisation, no host<->device
-// copies: every call is a sequence of asynchronous launches on the caller's stream.
+// 253-362 and main.cu:125-192 in the reference).  No allocation, no host<->device copies of data: every call is a
+// sequence of asynchronous launches on the caller's stream (rt_run_sah_build alone synchronises: its number of
+// levels is data dependent).
 #include "rt_device.hpp"
 #include "rt_launch.hpp"
 
@@ -138,6 +139,35 @@ int rt_run_bottom_up_build(const rt_build_input* input, const rt_arguments* args
     return hip_rc(e);
 }
 
+size_t rt_sah_memory_requirements(uint32_t num_triangles) { return sah_layout(num_triangles).total; }
+
+int rt_sah_scratch_layout_get(uint32_t num_triangles, rt_sah_scratch_layout* out)
+{
+    if (!out) return RT_ERR_INVALID_ARGUMENT;
+    const SahLayout L = sah_layout(num_triangles);
+    out->p_aabb = L.header;          // SahHeader starts with gp[6], gc[6]
+    out->c_aabb = L.header + 24;
+    out->status = L.status;
+    out->num_leaves = L.status + 4;
+    out->cell_counts = L.cell_counts;
+    out->total = L.total;
+    return RT_OK;
+}
+
+int rt_run_sah_build(const rt_build_input* input, const rt_arguments* args, void* stream)
+{
+    if (!input || !input->nodes_out || !input->scratch) return RT_ERR_INVALID_ARGUMENT;
+    const uint32_t n = input->num_triangles;
+    if (n && (!input->triangles_in || !input->triangles_out)) return RT_ERR_INVALID_ARGUMENT;
+    if (n > (1u << 28) - 64) return RT_ERR_TOO_LARGE;
+    if (args && args->enable_splits) return RT_ERR_UNSUPPORTED;  // SetupSplits / SetupPairSplits (Multiblock.cu:209-425)
+    if ((reinterpret_cast<uintptr_t>(input->scratch) & 255u) || (reinterpret_cast<uintptr_t>(input->triangles_in) & 15u) ||
+        (reinterpret_cast<uintptr_t>(input->triangles_out) & 63u) || (reinterpret_cast<uintptr_t>(input->nodes_out) & 63u))
+        return RT_ERR_INVALID_ARGUMENT;
+    return hip_rc(launch_sah_build(input->triangles_in, n, args && args->enable_pairs, input->triangles_out, input->nodes_out,
+                                   input->scratch, static_cast<hipStream_t>(stream), nullptr));
+}
+
 int rt_trace(const rt_accel* as, const rt_scene* scene, uint64_t* counters, int render_type, uint8_t* rgba8,
              uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t spp, void* stream)
 {
@@ -171,7 +201,7 @@ const char* rt_error_string(int code)
     switch (code) {
     case RT_OK: return "ok";
     case RT_ERR_INVALID_ARGUMENT: return "invalid argument";
-    case RT_ERR_UNSUPPORTED: return "unsupported option (splits / SAH builder)";
+    case RT_ERR_UNSUPPORTED: return "unsupported option (spatial splits)";
     case RT_ERR_TOO_LARGE: return "too many triangles for the 29-bit node index";
     default: break;
     }

@@ -61,6 +61,16 @@ struct BuLayout {
 };
 BuLayout bu_layout(uint32_t n);
 
+// ---- SAH build scratch (sah_build.hip)
+struct SahLayout {
+    size_t header, aabbs, ids0, ids1, task_of0, task_of1, binof, tasks0, tasks1, splits, bins0, bins1, chunk_hist,
+        chunk_prefix, small, sort, pair_flags, pair_sums;
+    size_t status;       // uint32[8] inside the header: [0] error flags, [1] number of leaves L
+    size_t cell_counts;  // uint32[64] inside the header
+    size_t total;
+};
+SahLayout sah_layout(uint32_t n);
+
 // ---- launches
 hipError_t launch_reset_aabb(int* aabb, hipStream_t st);
 hipError_t launch_scene_aabb(const rt_triangle* tris, uint32_t n, int* aabb, hipStream_t st);
@@ -74,6 +84,18 @@ hipError_t launch_radix_sort(uint32_t* keys, uint32_t* vals, uint32_t* tmp_keys,
 hipError_t launch_lbvh_levels(const rt_triangle* tris, const uint32_t* codes, const uint32_t* sorted_indices,
                               uint32_t n, rt_triangle_pair* leaves, rt_node* nodes, void* level_scratch,
                               uint32_t* status, hipStream_t st, const uint32_t* n_dev = nullptr);
+
+// one stable 8-bit pass (keys_in, vals_in) -> (keys_out, vals_out) on bits [shift, shift+8); *digit_total (device,
+// uint32[256], valid after the pass) = number of keys per digit
+hipError_t launch_radix_pass(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
+                             uint32_t n, uint32_t shift, void* sort_scratch, hipStream_t st, const uint32_t* n_dev,
+                             uint32_t** digit_total);
+// --pairs leaf slots: merge flag per candidate (2k, 2k+1), per-workgroup slot offsets, *num_leaves = L
+hipError_t launch_pair_slots(const rt_triangle* tris, uint32_t n, uint8_t* flags, uint32_t* block_sums,
+                             uint32_t* num_leaves, hipStream_t st);
+// RunSahBuild (no splits).  Synchronises the stream (data-dependent number of levels).
+hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, rt_triangle_pair* leaves, rt_node* nodes,
+                            void* scratch, hipStream_t st, uint32_t* levels_run);
 
 hipError_t launch_hybrid_top(rt_node* nodes, const int* aabb_ordered, uint32_t n, hipStream_t st,
                              const uint32_t* n_dev = nullptr);

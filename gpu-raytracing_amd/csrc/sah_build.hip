@@ -1,0 +1,886 @@
+// sah_build.hip -- the SAH build path for gfx950.
+//
+// Replaces RunSahBuild (BuildWrapper.cu:140-251) without spatial splits: Setup (Multiblock.cu:139-207),
+// GridBlockCounts / GridBlockScan / GridBlockDistribute (:427-546) and both SharedTaskBuild launches
+// (SharedTaskBuilder.cu:93-607, 909-967).  Same tree as the reference -- leaves bucketed by centroid into a
+// 4 x 4 x 4 grid, one top-down binned-SAH sub-tree per cell (8 bins on the longest centroid axis, leaf threshold 2,
+// object-median split when the centroid box has no area), a SAH top tree over the non-empty cells, trace root
+// (slot 0, count 1) -- with a different machine mapping and a DETERMINISTIC numbering (the rules are stated above
+// ora_build_sah in oracle/rt_oracle.c, which this file matches bit for bit):
+//
+//   * the reference builds each cell with ONE 512-thread block (64 blocks in total) looping over a task queue;
+//     here every task of every cell that is alive in a level is processed in the same launch:
+//       sah_bin_kernel       256 positions per workgroup; bins are aggregated in LDS per (task, bin) and flushed with
+//                            a handful of integer atomics (ordered-int min / max / add: order independent);
+//       sah_split_kernel     one wave per task: plane selection, parent descriptor, child tasks, and the per-chunk
+//                            prefix of "goes left" counts a task spanning several workgroups needs;
+//       sah_partition_kernel stable partition (block scan + that prefix) into the other id buffer;
+//     tasks of <= 32 items leave the level loop and are finished by sah_small_kernel, one thread per task
+//     (the reference's PerInstanceRunTask, SharedTaskBuilder.cu:742-907);
+//   * node slots are a function of the split POSITION (slot = bias + 2 * mid), not of an allocation counter, so no
+//     kernel needs to agree on an order and the top tree is built in the same launches as the cell trees;
+//   * leaf slots = input order (pairs: prefix sums), cell members by one stable 8-bit radix pass (radix_sort.hip).
+//
+// The level loop's length is data dependent; like the reference (which reads num_leaves back, BuildWrapper.cu:229)
+// the host synchronises: after the first batch of levels it reads the number of live tasks, then once per batch.
+#include "rt_device.hpp"
+#include "rt_launch.hpp"
+#include "rt_pairing.hpp"
+
+namespace rt {
+
+constexpr uint32_t kSahCells = 64;
+constexpr uint32_t kSahChunk = 256;       // positions per workgroup in the level kernels
+constexpr uint32_t kSahSmall = 32;        // tasks with <= 32 items are finished by one thread
+constexpr uint32_t kSahMaxLocal = 32;     // runs of equal task id a chunk can hold (tasks in the loop have >= 33 items)
+constexpr uint32_t kInactive = 0xFFFFFFFFu;
+constexpr uint32_t kSahMaxLevels = 1024;
+constexpr int kEmptyLo = 0x7f7fffff, kEmptyHi = (int)0x80800000;   // ordered-int FLT_MAX / -FLT_MAX (BuildWrapper.cu:170-171)
+constexpr uint32_t kBinWords = 13;        // p box [6], c box [6], count
+constexpr uint32_t kIdMask = 0x7FFFFFFFu; // bit 31 of an id: the leaf holds two triangles
+
+enum : uint32_t { kSahErrLocals = 0x100, kSahErrLevels = 0x200 };
+
+struct SahTask { float c[6]; float p[6]; uint32_t start, end, parent_idx, flags; };   // flags bit0: top tree
+struct SahSplit { uint32_t kind, plane, mid, left_id, right_id, pad[3]; };            // kind 1 binned, 2 median
+struct SahSmall { uint32_t start, end, parent_idx, flags; };   // flags bit0 top tree, bit1 id buffer, bit2 top root
+
+struct SahHeader {
+    int gp[6], gc[6];                  // scene primitive / centroid bounds, ordered ints
+    uint32_t status[8];                // [0] error flags, [1] number of leaves L
+    uint32_t small_count, pad[3];
+    uint32_t cell_count[kSahCells], cell_start[kSahCells], cell_task[kSahCells];
+    int cell_p[kSahCells][6], cell_c[kSahCells][6];
+    uint32_t level_count[kSahMaxLevels];
+};
+
+struct SahArgs {
+    SahHeader* H;
+    rt_node* nodes;
+    const float* aabbs;                // [n + 64][6]
+    uint32_t* ids[2];
+    uint32_t* task_of[2];
+    uint8_t* binof;
+    SahTask* tasks[2];
+    SahSplit* splits;
+    int* bins[2];                      // [task][8][13]
+    uint32_t* chunk_hist;              // [chunk][2][8]
+    uint32_t* chunk_prefix;            // [chunk]
+    SahSmall* small;
+    uint32_t n, M;                     // triangles; positions = n + 64
+};
+
+// ---- min / max on the ordered-int encoding (what the atomics compute)
+__device__ __forceinline__ float fmin_ord(float a, float b) { return float_to_ordered_int(a) < float_to_ordered_int(b) ? a : b; }
+__device__ __forceinline__ float fmax_ord(float a, float b) { return float_to_ordered_int(a) > float_to_ordered_int(b) ? a : b; }
+
+// float -> int as the reference's device converts it: NaN -> 0, saturating (make_int3 / int() in Multiblock.cu:447, SharedTaskBuilder.cu:222)
+__device__ __forceinline__ int cvt_rzi(float f)
+{
+    if (f != f) return 0;
+    return (int)fminf(fmaxf(f, -2147483648.0f), 2147483520.0f);
+}
+
+__device__ __forceinline__ float sah_sa(const float* b)   // Common.cuh:293-297
+{
+    const float lx = b[3] - b[0], ly = b[4] - b[1], lz = b[5] - b[2];
+    return 2.0f * (lx * ly + lx * lz + ly * lz);
+}
+
+__device__ __forceinline__ void sah_put_node(rt_node* n, const float* b, uint32_t child, uint32_t count, uint32_t type)
+{
+    uint4* o = reinterpret_cast<uint4*>(n);
+    o[0] = make_uint4(__float_as_uint(b[0]), __float_as_uint(b[1]), __float_as_uint(b[2]), count << 29);
+    o[1] = make_uint4(__float_as_uint(b[3]), __float_as_uint(b[4]), __float_as_uint(b[5]), (child & kIndexMask) | (type << 29));
+}
+
+__device__ __forceinline__ void load_box(const float* aabbs, uint32_t id, float* b)
+{
+    const float2* q = reinterpret_cast<const float2*>(aabbs + (size_t)id * 6);
+    const float2 a = q[0], c = q[1], d = q[2];
+    b[0] = a.x; b[1] = a.y; b[2] = c.x; b[3] = c.y; b[4] = d.x; b[5] = d.y;
+}
+
+// the leaf descriptor of one item (SharedTaskBuilder.cu:405-446): a triangle leaf, or -- in the top tree -- a cell,
+// written with count 0 as a marker and completed by sah_patch_top_kernel once the cell's sub-root exists
+__device__ __forceinline__ void sah_leaf_desc(const SahArgs& a, rt_node* out, uint32_t idv)
+{
+    const uint32_t id = idv & kIdMask;
+    float b[6];
+    load_box(a.aabbs, id, b);
+    if (id < a.n) sah_put_node(out, b, id, (idv >> 31) ? 2u : 1u, RT_CHILD_TRI);
+    else sah_put_node(out, b, id - a.n, 0u, RT_CHILD_BOX);
+}
+
+__device__ __forceinline__ int sah_axis(const float* c)   // SelectAxis (SharedTaskBuilder.cu:197-204)
+{
+    const float lx = c[3] - c[0], ly = c[4] - c[1], lz = c[5] - c[2];
+    return 2 * (lz > lx && lz > ly) + 1 * (ly > lx && ly >= lz);
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void sah_init_kernel(SahHeader* H, rt_node* nodes, uint32_t n)
+{
+    const uint32_t t = threadIdx.x;
+    if (t < 6) { H->gp[t] = t < 3 ? kEmptyLo : kEmptyHi; H->gc[t] = t < 3 ? kEmptyLo : kEmptyHi; }
+    if (t < 8) H->status[t] = t == 1 ? n : 0u;
+    if (t == 0) H->small_count = 0;
+    if (t < kSahCells) {
+        H->cell_count[t] = 0; H->cell_start[t] = 0; H->cell_task[t] = kInactive;
+        for (int k = 0; k < 6; k++) { H->cell_p[t][k] = k < 3 ? kEmptyLo : kEmptyHi; H->cell_c[t][k] = k < 3 ? kEmptyLo : kEmptyHi; }
+    }
+    for (uint32_t i = t; i < kSahMaxLevels; i += blockDim.x) H->level_count[i] = 0;
+    // the top tree's slots [0, 128): whatever the build does not write is type None
+    for (uint32_t i = t; i < 2 * kSahCells * 2; i += blockDim.x) reinterpret_cast<uint4*>(nodes)[i] = make_uint4(0, 0, 0, 0);
+}
+
+// Setup (Multiblock.cu:139-207): one thread per candidate (triangles 2k, 2k+1).  Leaf slot = input order.
+__global__ __launch_bounds__(256) void sah_setup_kernel(const float* __restrict__ f, uint32_t n,
+                                                        rt_triangle_pair* __restrict__ leaves, float* __restrict__ aabbs,
+                                                        uint32_t* __restrict__ idsv, SahHeader* H,
+                                                        const uint8_t* __restrict__ flags,
+                                                        const uint32_t* __restrict__ block_offsets)
+{
+    __shared__ int sb[12];
+    __shared__ uint32_t ws[8];
+    if (threadIdx.x < 12) sb[threadIdx.x] = (threadIdx.x % 6) < 3 ? kEmptyLo : kEmptyHi;
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x, tid = 2 * k;
+    const bool live = tid < n, second = tid + 1 < n;
+    const bool merge = live && flags && flags[k] != 0;
+    const uint32_t valid = live ? 1u + ((second && !merge) ? 1u : 0u) : 0u;
+    uint32_t slot = tid;
+    if (flags) {
+        uint32_t total;
+        slot = block_offsets[blockIdx.x] + block_excl_scan_u32<256>(valid, ws, &total);
+    } else {
+        __syncthreads();
+    }
+    if (live) {
+        float A[9], B[9];
+        load_tri9(f + (size_t)tid * 9, A);
+        load_tri9(f + (size_t)(second ? tid + 1 : tid) * 9, B);
+        float ab[6], bb[6];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            ab[j] = fminf(fminf(A[j], A[3 + j]), A[6 + j]); ab[3 + j] = fmaxf(fmaxf(A[j], A[3 + j]), A[6 + j]);
+            bb[j] = fminf(fminf(B[j], B[3 + j]), B[6 + j]); bb[3 + j] = fmaxf(fmaxf(B[j], B[3 + j]), B[6 + j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const float ac = (ab[j] + ab[3 + j]) * 0.5f, bc = (bb[j] + bb[3 + j]) * 0.5f;
+            atomicMin(&sb[j], min(float_to_ordered_int(ab[j]), float_to_ordered_int(bb[j])));
+            atomicMax(&sb[3 + j], max(float_to_ordered_int(ab[3 + j]), float_to_ordered_int(bb[3 + j])));
+            atomicMin(&sb[6 + j], min(float_to_ordered_int(ac), float_to_ordered_int(bc)));
+            atomicMax(&sb[9 + j], max(float_to_ordered_int(ac), float_to_ordered_int(bc)));
+        }
+        uint4* out = reinterpret_cast<uint4*>(leaves + slot);
+        float2* bo = reinterpret_cast<float2*>(aabbs + (size_t)slot * 6);
+        if (merge) {
+            // CreateTrianglePair (Pairing.cuh:60-77), as in the LBVH leaf kernel
+            int ra = 0, rb = 0;
+            can_form_pair(A, B, ra, rb);
+            float r[9], v3[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                r[j] = ra == 1 ? A[6 + j] : (ra == 2 ? A[3 + j] : A[j]);
+                r[3 + j] = ra == 1 ? A[j] : (ra == 2 ? A[6 + j] : A[3 + j]);
+                r[6 + j] = ra == 1 ? A[3 + j] : (ra == 2 ? A[j] : A[6 + j]);
+                v3[j] = rb == 2 ? B[j] : (rb == 1 ? B[3 + j] : B[6 + j]);
+            }
+            out[0] = make_uint4(__float_as_uint(r[0]), __float_as_uint(r[1]), __float_as_uint(r[2]), tid);
+            out[1] = make_uint4(__float_as_uint(r[3]), __float_as_uint(r[4]), __float_as_uint(r[5]), tid + 1);
+            out[2] = make_uint4(__float_as_uint(r[6]), __float_as_uint(r[7]), __float_as_uint(r[8]), (uint32_t)ra | ((uint32_t)rb << 16));
+            out[3] = make_uint4(__float_as_uint(v3[0]), __float_as_uint(v3[1]), __float_as_uint(v3[2]), 0u);
+            float u[6];
+#pragma unroll
+            for (int j = 0; j < 3; j++) { u[j] = fmin_ord(ab[j], bb[j]); u[3 + j] = fmax_ord(ab[3 + j], bb[3 + j]); }
+            bo[0] = make_float2(u[0], u[1]); bo[1] = make_float2(u[2], u[3]); bo[2] = make_float2(u[4], u[5]);
+            idsv[slot] = slot | 0x80000000u;
+        } else {
+            out[0] = make_uint4(__float_as_uint(A[0]), __float_as_uint(A[1]), __float_as_uint(A[2]), tid);
+            out[1] = make_uint4(__float_as_uint(A[3]), __float_as_uint(A[4]), __float_as_uint(A[5]), 0u);
+            out[2] = make_uint4(__float_as_uint(A[6]), __float_as_uint(A[7]), __float_as_uint(A[8]), 0u);
+            out[3] = make_uint4(__float_as_uint(A[6]), __float_as_uint(A[7]), __float_as_uint(A[8]), 0u);
+            bo[0] = make_float2(ab[0], ab[1]); bo[1] = make_float2(ab[2], ab[3]); bo[2] = make_float2(ab[4], ab[5]);
+            idsv[slot] = slot;
+            if (second) {
+                out[4] = make_uint4(__float_as_uint(B[0]), __float_as_uint(B[1]), __float_as_uint(B[2]), tid + 1);
+                out[5] = make_uint4(__float_as_uint(B[3]), __float_as_uint(B[4]), __float_as_uint(B[5]), 0u);
+                out[6] = make_uint4(__float_as_uint(B[6]), __float_as_uint(B[7]), __float_as_uint(B[8]), 0u);
+                out[7] = make_uint4(__float_as_uint(B[6]), __float_as_uint(B[7]), __float_as_uint(B[8]), 0u);
+                bo[3] = make_float2(bb[0], bb[1]); bo[4] = make_float2(bb[2], bb[3]); bo[5] = make_float2(bb[4], bb[5]);
+                idsv[slot + 1] = slot + 1;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        int* g = threadIdx.x < 6 ? &H->gp[threadIdx.x] : &H->gc[threadIdx.x - 6];
+        if ((threadIdx.x % 6) < 3) atomicMin(g, sb[threadIdx.x]); else atomicMax(g, sb[threadIdx.x]);
+    }
+}
+
+// GridBlockCounts (Multiblock.cu:427-468): the grid cell of every leaf (the key of the distribution pass) and the
+// per-cell primitive / centroid bounds.  The cell counts come out of the radix pass (its digit totals).
+__global__ __launch_bounds__(256) void sah_grid_kernel(const float* __restrict__ aabbs, uint32_t n, const uint32_t* n_dev,
+                                                       SahHeader* H, uint32_t* __restrict__ keys)
+{
+    const uint32_t L = n_dev ? *n_dev : n;
+    __shared__ int cp[kSahCells][6], cc[kSahCells][6];
+    __shared__ uint32_t cnt[kSahCells];
+    for (uint32_t j = threadIdx.x; j < kSahCells * 6; j += 256) {
+        (&cp[0][0])[j] = (j % 6) < 3 ? kEmptyLo : kEmptyHi;
+        (&cc[0][0])[j] = (j % 6) < 3 ? kEmptyLo : kEmptyHi;
+    }
+    if (threadIdx.x < kSahCells) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < L) {
+        float b[6];
+        load_box(aabbs, i, b);
+        const float epsilon = 1.1920929e-7f;
+        const float gscale = 4 * (1 - epsilon);
+        int q[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float lo = ordered_int_to_float(H->gc[k]), hi = ordered_int_to_float(H->gc[3 + k]);
+            const float ctr = (b[k] + b[3 + k]) * 0.5f;
+            q[k] = min(3, max(0, cvt_rzi((ctr - lo) * gscale / (hi - lo))));
+        }
+        const int cell = q[0] + q[1] * 4 + q[2] * 16;
+        keys[i] = (uint32_t)cell;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float ctr = (b[k] + b[3 + k]) * 0.5f;
+            atomicMin(&cp[cell][k], float_to_ordered_int(b[k]));
+            atomicMax(&cp[cell][3 + k], float_to_ordered_int(b[3 + k]));
+            atomicMin(&cc[cell][k], float_to_ordered_int(ctr));
+            atomicMax(&cc[cell][3 + k], float_to_ordered_int(ctr));
+        }
+        atomicAdd(&cnt[cell], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < kSahCells && cnt[threadIdx.x]) {
+        const uint32_t c = threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            atomicMin(&H->cell_p[c][k], cp[c][k]); atomicMax(&H->cell_p[c][3 + k], cp[c][3 + k]);
+            atomicMin(&H->cell_c[c][k], cc[c][k]); atomicMax(&H->cell_c[c][3 + k], cc[c][3 + k]);
+        }
+    }
+}
+
+__device__ __forceinline__ void sah_init_bins(int* bins, uint32_t task, uint32_t lane, uint32_t stride)
+{
+    for (uint32_t j = lane; j < 8 * kBinWords; j += stride) {
+        const uint32_t w = j % kBinWords;
+        bins[(size_t)task * 8 * kBinWords + j] = w == 12 ? 0 : ((w % 6) < 3 ? kEmptyLo : kEmptyHi);
+    }
+}
+
+// GridBlockScan + the task set-up of SharedTaskBuild::Initialise (Multiblock.cu:470-505, SharedTaskBuilder.cu:93-135):
+// cell starts, cell boxes as the top tree's items, the root task of every non-empty cell and of the top tree.
+__global__ __launch_bounds__(128) void sah_roots_kernel(SahArgs a, const uint32_t* __restrict__ digit_total, float* aabbs_w)
+{
+    __shared__ uint32_t ws[4];
+    SahHeader* H = a.H;
+    const uint32_t t = threadIdx.x;
+    const uint32_t cnt = t < kSahCells ? digit_total[t] : 0u;
+    uint32_t total, K;
+    const uint32_t start = block_excl_scan_u32<128>(cnt, ws, &total);
+    const uint32_t k = block_excl_scan_u32<128>(cnt ? 1u : 0u, ws, &K);
+    if (t < kSahCells) {
+        H->cell_count[t] = cnt;
+        H->cell_start[t] = start;
+        float pb[6], cb[6];
+        for (int j = 0; j < 6; j++) { pb[j] = ordered_int_to_float(H->cell_p[t][j]); cb[j] = ordered_int_to_float(H->cell_c[t][j]); }
+        for (int j = 0; j < 6; j++) aabbs_w[(size_t)(a.n + t) * 6 + j] = pb[j];
+        uint32_t task = kInactive;
+        if (cnt) {
+            a.ids[0][a.n + k] = a.n + t;
+            const uint32_t parent = 2 * kSahCells + 2 * start;
+            reinterpret_cast<uint4*>(a.nodes + parent + 1)[0] = make_uint4(0, 0, 0, 0);   // the root's sibling slot: None
+            reinterpret_cast<uint4*>(a.nodes + parent + 1)[1] = make_uint4(0, 0, 0, 0);
+            if (cnt > kSahSmall) {
+                task = atomicAdd(&H->level_count[0], 1u);
+                SahTask T;
+                for (int j = 0; j < 6; j++) { T.c[j] = cb[j]; T.p[j] = pb[j]; }
+                T.start = start; T.end = start + cnt; T.parent_idx = parent; T.flags = 0;
+                a.tasks[0][task] = T;
+                sah_init_bins(a.bins[0], task, 0, 1);
+            } else {
+                const uint32_t s = atomicAdd(&H->small_count, 1u);
+                a.small[s] = SahSmall{start, start + cnt, parent, 0u};
+            }
+        }
+        H->cell_task[t] = task;
+    }
+    __syncthreads();
+    if (t == 64) {   // the top tree: items = the K non-empty cells at positions [n, n + K), root descriptor = slot 0
+        uint32_t task = kInactive;
+        if (K > kSahSmall) {
+            task = atomicAdd(&H->level_count[0], 1u);
+            SahTask T;
+            for (int j = 0; j < 6; j++) { T.c[j] = ordered_int_to_float(H->gc[j]); T.p[j] = ordered_int_to_float(H->gp[j]); }
+            T.start = a.n; T.end = a.n + K; T.parent_idx = 0; T.flags = 1;
+            a.tasks[0][task] = T;
+            sah_init_bins(a.bins[0], task, 0, 1);
+        } else if (K) {
+            const uint32_t s = atomicAdd(&H->small_count, 1u);
+            a.small[s] = SahSmall{a.n, a.n + K, 0u, 1u | 4u};
+        }
+        for (uint32_t j = 0; j < kSahCells; j++) a.task_of[0][a.n + j] = j < K ? task : kInactive;
+    }
+}
+
+// position -> root task of its cell (the sorted keys of the distribution pass are the cell ids)
+__global__ __launch_bounds__(256) void sah_assign_kernel(SahArgs a, const uint32_t* n_dev)
+{
+    const uint32_t L = n_dev ? *n_dev : a.n;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    a.task_of[0][i] = i < L ? a.H->cell_task[a.task_of[0][i] & (kSahCells - 1)] : kInactive;
+}
+
+// ---------------------------------------------------------------------------------------------
+// runs of equal task id inside a chunk: local index of this position's run, number of runs
+__device__ __forceinline__ uint32_t sah_local_runs(uint32_t t, uint32_t t_prev, uint32_t* ws, uint32_t* nloc)
+{
+    const uint32_t flag = (threadIdx.x > 0 && t != t_prev) ? 1u : 0u;
+    uint32_t total;
+    const uint32_t ex = block_excl_scan_u32<256>(flag, ws, &total);
+    *nloc = total + 1;
+    return ex + flag;
+}
+
+// BinCentroids (SharedTaskBuilder.cu:206-264) for every task alive in level `lvl`
+__global__ __launch_bounds__(256) void sah_bin_kernel(SahArgs a, uint32_t lvl)
+{
+    if (a.H->level_count[lvl] == 0) return;
+    const uint32_t cur = lvl & 1;
+    __shared__ int lbins[kSahMaxLocal][8][kBinWords];
+    __shared__ uint32_t ltask[kSahMaxLocal];
+    __shared__ uint32_t ws[8];
+    const uint32_t chunk = blockIdx.x, pos = chunk * kSahChunk + threadIdx.x;
+    const uint32_t t = pos < a.M ? a.task_of[cur][pos] : kInactive;
+    const uint32_t t_prev = (threadIdx.x > 0 && pos - 1 < a.M) ? a.task_of[cur][pos - 1] : kInactive;
+    for (uint32_t j = threadIdx.x; j < kSahMaxLocal * 8 * kBinWords; j += 256) {
+        const uint32_t w = j % kBinWords;
+        (&lbins[0][0][0])[j] = w == 12 ? 0 : ((w % 6) < 3 ? kEmptyLo : kEmptyHi);
+    }
+    uint32_t nloc;
+    const uint32_t local = sah_local_runs(t, t_prev, ws, &nloc);   // ends with a barrier
+    if (nloc > kSahMaxLocal) {
+        if (threadIdx.x == 0) atomicOr(&a.H->status[0], kSahErrLocals);
+        return;
+    }
+    if (threadIdx.x == 0 || t != t_prev) ltask[local] = t;
+    if (t != kInactive) {
+        const SahTask* T = &a.tasks[cur][t];
+        float c[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) c[k] = T->c[k];
+        if (!(sah_sa(c) <= 0.0f)) {
+            const int axis = sah_axis(c);
+            const float epsilon = 1.1920929e-7f;
+            const float cmin = axis == 0 ? c[0] : (axis == 1 ? c[1] : c[2]);
+            const float cmax = axis == 0 ? c[3] : (axis == 1 ? c[4] : c[5]);
+            const float k1 = 8 * (1 - epsilon) / (cmax - cmin);
+            const uint32_t id = a.ids[cur][pos] & kIdMask;
+            float b[6];
+            load_box(a.aabbs, id, b);
+            float ctr[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) ctr[k] = (b[k] + b[3 + k]) * 0.5f;
+            const float ca = axis == 0 ? ctr[0] : (axis == 1 ? ctr[1] : ctr[2]);
+            const int bin = min(7, max(0, cvt_rzi(k1 * (ca - cmin))));   // the reference aborts the build on an out-of-range bin
+            a.binof[pos] = (uint8_t)bin;
+            int* lb = &lbins[local][bin][0];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                atomicMin(&lb[k], float_to_ordered_int(b[k]));
+                atomicMax(&lb[3 + k], float_to_ordered_int(b[3 + k]));
+                atomicMin(&lb[6 + k], float_to_ordered_int(ctr[k]));
+                atomicMax(&lb[9 + k], float_to_ordered_int(ctr[k]));
+            }
+            atomicAdd(&lb[12], 1);
+        }
+    }
+    __syncthreads();
+    {
+        const uint32_t l = threadIdx.x >> 3, bin = threadIdx.x & 7;
+        if (l < nloc && lbins[l][bin][12] > 0) {
+            int* g = a.bins[cur] + ((size_t)ltask[l] * 8 + bin) * kBinWords;
+            const int* s = &lbins[l][bin][0];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                atomicMin(&g[k], s[k]); atomicMax(&g[3 + k], s[3 + k]);
+                atomicMin(&g[6 + k], s[6 + k]); atomicMax(&g[9 + k], s[9 + k]);
+            }
+            atomicAdd(&g[12], s[12]);
+        }
+    }
+    // the bin histogram of the first and of the last run: what a task spanning several chunks needs for its partition
+    if (threadIdx.x < 8) a.chunk_hist[(size_t)chunk * 16 + threadIdx.x] = (uint32_t)lbins[0][threadIdx.x][12];
+    else if (threadIdx.x < 16) a.chunk_hist[(size_t)chunk * 16 + threadIdx.x] = (uint32_t)lbins[nloc - 1][threadIdx.x - 8][12];
+}
+
+__device__ __forceinline__ void ibox_merge(int* b, const int* o)
+{
+#pragma unroll
+    for (int k = 0; k < 3; k++) { b[k] = min(b[k], o[k]); b[3 + k] = max(b[3 + k], o[3 + k]); }
+}
+__device__ __forceinline__ void ibox_to_float(const int* b, float* f)
+{
+#pragma unroll
+    for (int k = 0; k < 6; k++) f[k] = ordered_int_to_float(b[k]);
+}
+
+// SelectPlane (SharedTaskBuilder.cu:297-350) on 8 bins of 13 ints.  Returns the plane (or -1) and the child boxes.
+__device__ __forceinline__ int sah_select_plane(const int (*bin)[kBinWords], int* lp_out, int* lc_out, int* rp_out,
+                                                int* rc_out, uint32_t* nl_out)
+{
+    int lp[7][6], lc[7][6];
+    uint32_t ln[7];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { lp[0][k] = bin[0][k]; lc[0][k] = bin[0][6 + k]; }
+    ln[0] = (uint32_t)bin[0][12];
+#pragma unroll
+    for (int i = 1; i < 7; i++) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) { lp[i][k] = lp[i - 1][k]; lc[i][k] = lc[i - 1][k]; }
+        ibox_merge(lp[i], &bin[i][0]);
+        ibox_merge(lc[i], &bin[i][6]);
+        ln[i] = ln[i - 1] + (uint32_t)bin[i][12];
+    }
+    int rp[6], rc[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { rp[k] = bin[7][k]; rc[k] = bin[7][6 + k]; }
+    uint32_t rn = (uint32_t)bin[7][12];
+    float best = 3.402823466e+38f;
+    int plane = -1;
+#pragma unroll
+    for (int i = 6; i >= 0; i--) {
+        float lf[6], rf[6];
+        ibox_to_float(lp[i], lf);
+        ibox_to_float(rp, rf);
+        const float score = sah_sa(lf) * (float)ln[i] + sah_sa(rf) * (float)rn;
+        if (score < best && ln[i] && rn) {
+            best = score; plane = i;
+            *nl_out = ln[i];
+#pragma unroll
+            for (int k = 0; k < 6; k++) { lp_out[k] = lp[i][k]; lc_out[k] = lc[i][k]; rp_out[k] = rp[k]; rc_out[k] = rc[k]; }
+        }
+        ibox_merge(rp, &bin[i][0]);
+        ibox_merge(rc, &bin[i][6]);
+        rn += (uint32_t)bin[i][12];
+    }
+    return plane;
+}
+
+// one wave per task: plane, parent descriptor, children (RunTask after the bins are known, SharedTaskBuilder.cu:521-606)
+__global__ __launch_bounds__(256) void sah_split_kernel(SahArgs a, uint32_t lvl)
+{
+    const uint32_t ntask = a.H->level_count[lvl];
+    const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (w >= ntask) return;
+    const uint32_t cur = lvl & 1, nxt = cur ^ 1;
+    const uint32_t lane = threadIdx.x & 63;
+    const SahTask T = a.tasks[cur][w];
+    const uint32_t count = T.end - T.start;
+    const int bias = (T.flags & 1u) ? -2 * (int)a.n : (int)(2 * kSahCells);
+
+    int cb[2][12];   // child boxes, ordered ints: [side][p box 6, c box 6]
+    uint32_t mid = 0, kind = 2, plane = 0;
+    if (!(sah_sa(T.c) <= 0.0f)) {
+        int bin[8][kBinWords];
+        const int* g = a.bins[cur] + (size_t)w * 8 * kBinWords;
+#pragma unroll
+        for (int b = 0; b < 8; b++)
+#pragma unroll
+            for (int k = 0; k < (int)kBinWords; k++) bin[b][k] = g[b * kBinWords + k];
+        uint32_t nl = 0;
+        const int pl = sah_select_plane(bin, &cb[0][0], &cb[0][6], &cb[1][0], &cb[1][6], &nl);
+        if (pl >= 0) { kind = 1; plane = (uint32_t)pl; mid = T.start + nl; }
+    }
+    if (kind == 2) {
+        // object split at the midpoint (SharedTaskBuilder.cu:465-510): child boxes by a wave reduction over the items
+        mid = T.start + (count >> 1);
+        int v[2][12];
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+#pragma unroll
+            for (int k = 0; k < 12; k++) v[s][k] = (k % 6) < 3 ? kEmptyLo : kEmptyHi;
+        for (uint32_t i = T.start + lane; i < T.end; i += 64) {
+            float b[6];
+            load_box(a.aabbs, a.ids[cur][i] & kIdMask, b);
+            const int s = i >= mid;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int ctr = float_to_ordered_int((b[3 + k] + b[k]) * 0.5f);
+                const int lo = float_to_ordered_int(b[k]), hi = float_to_ordered_int(b[3 + k]);
+                if (s) { v[1][k] = min(v[1][k], lo); v[1][3 + k] = max(v[1][3 + k], hi); v[1][6 + k] = min(v[1][6 + k], ctr); v[1][9 + k] = max(v[1][9 + k], ctr); }
+                else { v[0][k] = min(v[0][k], lo); v[0][3 + k] = max(v[0][3 + k], hi); v[0][6 + k] = min(v[0][6 + k], ctr); v[0][9 + k] = max(v[0][9 + k], ctr); }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+#pragma unroll
+            for (int k = 0; k < 12; k++) cb[s][k] = (k % 6) < 3 ? wave_min_i32(v[s][k]) : wave_max_i32(v[s][k]);
+    }
+    const uint32_t child_index = (uint32_t)(bias + 2 * (int)mid);
+    const uint32_t cs[2] = {T.start, mid}, ce[2] = {mid, T.end};
+    uint32_t cid[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        const uint32_t cc = ce[s] - cs[s];
+        uint32_t id = kInactive;
+        if (cc > kSahSmall) {
+            if (lane == 0) id = atomicAdd(&a.H->level_count[lvl + 1], 1u);
+            id = __builtin_amdgcn_readfirstlane(id);
+            if (lane == 0) {
+                SahTask C;
+                for (int k = 0; k < 6; k++) { C.p[k] = ordered_int_to_float(cb[s][k]); C.c[k] = ordered_int_to_float(cb[s][6 + k]); }
+                C.start = cs[s]; C.end = ce[s]; C.parent_idx = child_index + s; C.flags = T.flags;
+                a.tasks[nxt][id] = C;
+            }
+            sah_init_bins(a.bins[nxt], id, lane, 64);
+        } else if (lane == 0) {
+            const uint32_t sidx = atomicAdd(&a.H->small_count, 1u);
+            a.small[sidx] = SahSmall{cs[s], ce[s], child_index + s, (T.flags & 1u) | (nxt << 1)};
+        }
+        cid[s] = id;
+    }
+    if (lane == 0) {
+        sah_put_node(a.nodes + T.parent_idx, T.p, child_index, 2u, RT_CHILD_BOX);
+        SahSplit S;
+        S.kind = kind; S.plane = plane; S.mid = mid; S.left_id = cid[0]; S.right_id = cid[1];
+        S.pad[0] = S.pad[1] = S.pad[2] = 0;
+        a.splits[w] = S;
+    }
+    // "goes left" prefix per chunk for a task that spans several chunks (stable partition across workgroups)
+    const uint32_t c0 = T.start / kSahChunk, c1 = (T.end - 1) / kSahChunk;
+    if (kind == 1 && c1 > c0) {
+        uint32_t running = 0;
+        for (uint32_t base = c0; base <= c1; base += 64) {
+            const uint32_t c = base + lane;
+            uint32_t v = 0;
+            if (c <= c1) {
+                const uint32_t* h = a.chunk_hist + (size_t)c * 16 + (c == c0 ? 8 : 0);
+                for (uint32_t b = 0; b <= plane; b++) v += h[b];
+            }
+            const uint32_t incl = wave_incl_scan_u32(v, (int)lane);
+            if (c <= c1 && c > c0) a.chunk_prefix[c] = running + incl - v;
+            running += __shfl(incl, 63, 64);
+        }
+    }
+}
+
+// PartitionIds (SharedTaskBuilder.cu:352-380), stable: ids and the children's task ids go to the other buffer
+__global__ __launch_bounds__(256) void sah_partition_kernel(SahArgs a, uint32_t lvl)
+{
+    if (a.H->level_count[lvl] == 0) return;
+    const uint32_t cur = lvl & 1, nxt = cur ^ 1;
+    __shared__ uint32_t lfirst[kSahMaxLocal];
+    __shared__ uint32_t ws[8];
+    const uint32_t chunk = blockIdx.x, pos = chunk * kSahChunk + threadIdx.x;
+    const uint32_t t = pos < a.M ? a.task_of[cur][pos] : kInactive;
+    const uint32_t t_prev = (threadIdx.x > 0 && pos - 1 < a.M) ? a.task_of[cur][pos - 1] : kInactive;
+    uint32_t nloc;
+    const uint32_t local = sah_local_runs(t, t_prev, ws, &nloc);
+    if (nloc > kSahMaxLocal) return;   // reported by sah_bin_kernel
+    SahSplit S = {};
+    uint32_t start = 0;
+    bool left = false;
+    if (t != kInactive) {
+        S = a.splits[t];
+        start = a.tasks[cur][t].start;
+        left = S.kind == 1 ? (a.binof[pos] <= S.plane) : (pos < S.mid);
+    }
+    uint32_t total;
+    const uint32_t ex = block_excl_scan_u32<256>((t != kInactive && S.kind == 1 && left) ? 1u : 0u, ws, &total);
+    if (threadIdx.x == 0 || t != t_prev) lfirst[local] = ex;
+    __syncthreads();
+    if (pos >= a.M) return;
+    if (t == kInactive) { a.task_of[nxt][pos] = kInactive; return; }
+    uint32_t dest = pos;
+    if (S.kind == 1) {
+        const uint32_t before = start < chunk * kSahChunk ? a.chunk_prefix[chunk] : 0u;
+        const uint32_t lr = before + (ex - lfirst[local]);
+        dest = left ? start + lr : S.mid + ((pos - start) - lr);
+    }
+    a.ids[nxt][dest] = a.ids[cur][pos];
+    a.task_of[nxt][dest] = left ? S.left_id : S.right_id;
+}
+
+// ---------------------------------------------------------------------------------------------
+// one thread per small task: the whole sub-tree, depth first (PerInstanceRunTask, SharedTaskBuilder.cu:742-907)
+__global__ __launch_bounds__(64) void sah_small_kernel(SahArgs a)
+{
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= a.H->small_count) return;
+    const SahSmall R = a.small[i];
+    const int bias = (R.flags & 1u) ? -2 * (int)a.n : (int)(2 * kSahCells);
+    const uint32_t base = R.start;
+    uint32_t idbuf[2][kSahSmall];
+    {
+        const uint32_t* src = a.ids[(R.flags >> 1) & 1u];
+        for (uint32_t k = 0; k < R.end - R.start; k++) idbuf[0][k] = src[R.start + k];
+    }
+    uint32_t s_start[kSahSmall], s_end[kSahSmall], s_parent[kSahSmall], s_buf[kSahSmall];
+    uint32_t sp = 0;
+    s_start[0] = R.start; s_end[0] = R.end; s_parent[0] = R.parent_idx; s_buf[0] = 0;
+    sp = 1;
+    bool use_gc = (R.flags & 4u) != 0;   // the top root's centroid bounds are the scene's (BuildWrapper.cu:245-249)
+    while (sp) {
+        --sp;
+        const uint32_t ts = s_start[sp], te = s_end[sp], parent = s_parent[sp], buf = s_buf[sp];
+        const uint32_t count = te - ts;
+        const uint32_t* in = idbuf[buf];
+        uint32_t* out = idbuf[buf ^ 1];
+        int pi[6], ci[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { pi[k] = k < 3 ? kEmptyLo : kEmptyHi; ci[k] = pi[k]; }
+        for (uint32_t p = ts; p < te; p++) {
+            float b[6];
+            load_box(a.aabbs, in[p - base] & kIdMask, b);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int ctr = float_to_ordered_int((b[k] + b[3 + k]) * 0.5f);
+                pi[k] = min(pi[k], float_to_ordered_int(b[k])); pi[3 + k] = max(pi[3 + k], float_to_ordered_int(b[3 + k]));
+                ci[k] = min(ci[k], ctr); ci[3 + k] = max(ci[3 + k], ctr);
+            }
+        }
+        float pbox[6], cbox[6];
+        ibox_to_float(pi, pbox);
+        if (use_gc) { for (int k = 0; k < 6; k++) cbox[k] = ordered_int_to_float(a.H->gc[k]); }
+        else ibox_to_float(ci, cbox);
+        use_gc = false;
+        if (count <= 2) {
+            if (count == 1) { sah_leaf_desc(a, a.nodes + parent, in[ts - base]); continue; }
+            const uint32_t child = (uint32_t)(bias + 2 * (int)(ts + 1));
+            sah_leaf_desc(a, a.nodes + child, in[ts - base]);
+            sah_leaf_desc(a, a.nodes + child + 1, in[ts + 1 - base]);
+            sah_put_node(a.nodes + parent, pbox, child, 2u, RT_CHILD_BOX);
+            continue;
+        }
+        uint32_t mid = 0;
+        bool done = false;
+        if (!(sah_sa(cbox) <= 0.0f)) {
+            const int axis = sah_axis(cbox);
+            const float epsilon = 1.1920929e-7f;
+            const float cmin = axis == 0 ? cbox[0] : (axis == 1 ? cbox[1] : cbox[2]);
+            const float cmax = axis == 0 ? cbox[3] : (axis == 1 ? cbox[4] : cbox[5]);
+            const float k1 = 8 * (1 - epsilon) / (cmax - cmin);
+            int bp[8][6];
+            uint32_t bn[8];
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                bn[b] = 0;
+#pragma unroll
+                for (int k = 0; k < 6; k++) bp[b][k] = k < 3 ? kEmptyLo : kEmptyHi;
+            }
+            uint64_t binmask[2] = {0, 0};   // 3 bits per item, 32 items
+            for (uint32_t p = ts; p < te; p++) {
+                float b[6];
+                load_box(a.aabbs, in[p - base] & kIdMask, b);
+                const float ca = axis == 0 ? (b[0] + b[3]) * 0.5f : (axis == 1 ? (b[1] + b[4]) * 0.5f : (b[2] + b[5]) * 0.5f);
+                const int bin = min(7, max(0, cvt_rzi(k1 * (ca - cmin))));
+                const uint32_t q = p - ts;
+                binmask[q >> 4] |= (uint64_t)bin << ((q & 15) * 4);
+#pragma unroll
+                for (int bb = 0; bb < 8; bb++) {
+                    if (bb == bin) {
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            bp[bb][k] = min(bp[bb][k], float_to_ordered_int(b[k]));
+                            bp[bb][3 + k] = max(bp[bb][3 + k], float_to_ordered_int(b[3 + k]));
+                        }
+                        bn[bb]++;
+                    }
+                }
+            }
+            // SelectPlane on the primitive boxes only (the children recompute their centroid bounds on entry)
+            int lp[7][6];
+            uint32_t ln[7];
+#pragma unroll
+            for (int k = 0; k < 6; k++) lp[0][k] = bp[0][k];
+            ln[0] = bn[0];
+#pragma unroll
+            for (int j = 1; j < 7; j++) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) lp[j][k] = lp[j - 1][k];
+                ibox_merge(lp[j], bp[j]);
+                ln[j] = ln[j - 1] + bn[j];
+            }
+            int rp[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) rp[k] = bp[7][k];
+            uint32_t rn = bn[7];
+            float best = 3.402823466e+38f;
+            int plane = -1;
+            uint32_t nl = 0;
+#pragma unroll
+            for (int j = 6; j >= 0; j--) {
+                float lf[6], rf[6];
+                ibox_to_float(lp[j], lf);
+                ibox_to_float(rp, rf);
+                const float score = sah_sa(lf) * (float)ln[j] + sah_sa(rf) * (float)rn;
+                if (score < best && ln[j] && rn) { best = score; plane = j; nl = ln[j]; }
+                ibox_merge(rp, bp[j]);
+                rn += bn[j];
+            }
+            if (plane >= 0) {
+                uint32_t wl = ts, wr = ts + nl;
+                for (uint32_t p = ts; p < te; p++) {
+                    const uint32_t q = p - ts;
+                    const int bin = (int)((binmask[q >> 4] >> ((q & 15) * 4)) & 15u);
+                    if (bin <= plane) out[wl++ - base] = in[p - base];
+                    else out[wr++ - base] = in[p - base];
+                }
+                mid = ts + nl;
+                done = true;
+            }
+        }
+        if (!done) {
+            mid = ts + (count >> 1);
+            for (uint32_t p = ts; p < te; p++) out[p - base] = in[p - base];
+        }
+        const uint32_t child_index = (uint32_t)(bias + 2 * (int)mid);
+        sah_put_node(a.nodes + parent, pbox, child_index, 2u, RT_CHILD_BOX);
+        s_start[sp] = mid; s_end[sp] = te; s_parent[sp] = child_index + 1; s_buf[sp] = buf ^ 1; sp++;
+        s_start[sp] = ts; s_end[sp] = mid; s_parent[sp] = child_index; s_buf[sp] = buf ^ 1; sp++;
+    }
+}
+
+// top-tree leaves: copy child / count / type of the cell's sub-root (SharedTaskBuilder.cu:422-446; the reference
+// forces type Box, which breaks a cell that holds a single leaf -- the type is copied here)
+__global__ void sah_patch_top_kernel(SahArgs a)
+{
+    const uint32_t s = threadIdx.x;
+    if (s >= 2 * kSahCells) return;
+    rt_node* nd = a.nodes + s;
+    if ((nd->w28 >> 29) != RT_CHILD_BOX || (nd->w12 >> 29) != 0) return;
+    const uint32_t cell = nd->w28 & kIndexMask;
+    const rt_node* sub = a.nodes + 2 * kSahCells + 2 * a.H->cell_start[cell];
+    nd->w12 = sub->w12 & ~kIndexMask;
+    nd->w28 = sub->w28;
+}
+
+// ---------------------------------------------------------------------------------------------
+SahLayout sah_layout(uint32_t n)
+{
+    SahLayout L;
+    const size_t M = (size_t)n + kSahCells;
+    const size_t TA = M / (kSahSmall + 1) + 2;
+    const size_t chunks = (M + kSahChunk - 1) / kSahChunk;
+    auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+    size_t off = 0;
+    L.header = off;       off = al(off + sizeof(SahHeader));
+    L.aabbs = off;        off = al(off + M * 24);
+    L.ids0 = off;         off = al(off + M * 4);
+    L.ids1 = off;         off = al(off + M * 4);
+    L.task_of0 = off;     off = al(off + M * 4);
+    L.task_of1 = off;     off = al(off + M * 4);
+    L.binof = off;        off = al(off + M);
+    L.tasks0 = off;       off = al(off + TA * sizeof(SahTask));
+    L.tasks1 = off;       off = al(off + TA * sizeof(SahTask));
+    L.splits = off;       off = al(off + TA * sizeof(SahSplit));
+    L.bins0 = off;        off = al(off + TA * 8 * kBinWords * 4);
+    L.bins1 = off;        off = al(off + TA * 8 * kBinWords * 4);
+    L.chunk_hist = off;   off = al(off + chunks * 16 * 4);
+    L.chunk_prefix = off; off = al(off + chunks * 4);
+    L.small = off;        off = al(off + M * sizeof(SahSmall));
+    L.sort = off;         off = al(off + sort_scratch_layout(n).total);
+    L.pair_flags = off;   off = al(off + ((size_t)n + 1) / 2 + 1);
+    L.pair_sums = off;    off = al(off + (((size_t)n + 1) / 2 / 256 + 2) * 4);
+    L.status = L.header + offsetof(SahHeader, status);
+    L.cell_counts = L.header + offsetof(SahHeader, cell_count);
+    L.total = off;
+    return L;
+}
+
+hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, rt_triangle_pair* leaves, rt_node* nodes,
+                            void* scratch, hipStream_t st, uint32_t* levels_run)
+{
+    const SahLayout L = sah_layout(n);
+    char* s = static_cast<char*>(scratch);
+    SahArgs a;
+    a.H = reinterpret_cast<SahHeader*>(s + L.header);
+    a.nodes = nodes;
+    float* aabbs = reinterpret_cast<float*>(s + L.aabbs);
+    a.aabbs = aabbs;
+    a.ids[0] = reinterpret_cast<uint32_t*>(s + L.ids0);
+    a.ids[1] = reinterpret_cast<uint32_t*>(s + L.ids1);
+    a.task_of[0] = reinterpret_cast<uint32_t*>(s + L.task_of0);
+    a.task_of[1] = reinterpret_cast<uint32_t*>(s + L.task_of1);
+    a.binof = reinterpret_cast<uint8_t*>(s + L.binof);
+    a.tasks[0] = reinterpret_cast<SahTask*>(s + L.tasks0);
+    a.tasks[1] = reinterpret_cast<SahTask*>(s + L.tasks1);
+    a.splits = reinterpret_cast<SahSplit*>(s + L.splits);
+    a.bins[0] = reinterpret_cast<int*>(s + L.bins0);
+    a.bins[1] = reinterpret_cast<int*>(s + L.bins1);
+    a.chunk_hist = reinterpret_cast<uint32_t*>(s + L.chunk_hist);
+    a.chunk_prefix = reinterpret_cast<uint32_t*>(s + L.chunk_prefix);
+    a.small = reinterpret_cast<SahSmall*>(s + L.small);
+    a.n = n;
+    a.M = n + kSahCells;
+    uint32_t* num_leaves = &a.H->status[1];
+    const uint32_t* n_dev = pairs ? num_leaves : nullptr;
+    if (levels_run) *levels_run = 0;
+
+    sah_init_kernel<<<1, 256, 0, st>>>(a.H, nodes, n);
+    if (n == 0) return hipGetLastError();
+    const uint32_t cand = (n + 1) / 2, cblocks = (cand + 255) / 256;
+    uint8_t* pflags = nullptr;
+    uint32_t* psums = nullptr;
+    if (pairs) {
+        pflags = reinterpret_cast<uint8_t*>(s + L.pair_flags);
+        psums = reinterpret_cast<uint32_t*>(s + L.pair_sums);
+        hipError_t e = launch_pair_slots(tris, n, pflags, psums, num_leaves, st);
+        if (e != hipSuccess) return e;
+    }
+    sah_setup_kernel<<<cblocks, 256, 0, st>>>(reinterpret_cast<const float*>(tris), n, leaves, aabbs, a.ids[1], a.H, pflags, psums);
+    sah_grid_kernel<<<(n + 255) / 256, 256, 0, st>>>(aabbs, n, n_dev, a.H, a.task_of[1]);
+    // GridBlockDistribute: cell members in ascending leaf index = one stable radix pass on the cell id
+    uint32_t* digit_total = nullptr;
+    hipError_t e = launch_radix_pass(a.task_of[1], a.ids[1], a.task_of[0], a.ids[0], n, 0, s + L.sort, st, n_dev, &digit_total);
+    if (e != hipSuccess) return e;
+    sah_roots_kernel<<<1, 128, 0, st>>>(a, digit_total, aabbs);
+    sah_assign_kernel<<<(n + 255) / 256, 256, 0, st>>>(a, n_dev);
+
+    const uint32_t chunks = (a.M + kSahChunk - 1) / kSahChunk;
+    const uint32_t TA = a.M / (kSahSmall + 1) + 2;
+    const uint32_t split_blocks = (TA + 3) / 4;
+    uint32_t lvl = 0;
+    uint32_t batch = 16;
+    while (true) {
+        for (uint32_t i = 0; i < batch && lvl + 1 < kSahMaxLevels; i++, lvl++) {
+            sah_bin_kernel<<<chunks, 256, 0, st>>>(a, lvl);
+            sah_split_kernel<<<split_blocks, 256, 0, st>>>(a, lvl);
+            sah_partition_kernel<<<chunks, 256, 0, st>>>(a, lvl);
+        }
+        uint32_t live = 0;
+        e = hipMemcpyAsync(&live, &a.H->level_count[lvl], 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return e;
+        if (live == 0) break;
+        if (lvl + 1 >= kSahMaxLevels) {
+            const uint32_t flag = kSahErrLevels;
+            (void)hipMemcpyAsync(&a.H->status[0], &flag, 4, hipMemcpyHostToDevice, st);
+            (void)hipStreamSynchronize(st);
+            break;
+        }
+        batch = 8;
+    }
+    if (levels_run) *levels_run = lvl;
+    uint32_t nsmall = 0;
+    e = hipMemcpyAsync(&nsmall, &a.H->small_count, 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return e;
+    if (nsmall) sah_small_kernel<<<(nsmall + 63) / 64, 64, 0, st>>>(a);
+    sah_patch_top_kernel<<<1, 128, 0, st>>>(a);
+    return hipGetLastError();
+}
+
+}  // namespace rt

@@ -110,7 +110,7 @@ typedef struct rt_scene {
 enum {
     RT_OK = 0,
     RT_ERR_INVALID_ARGUMENT = -1,
-    RT_ERR_UNSUPPORTED = -2,       /* splits / SAH builder: SURVEY 8(f) "next" rows */
+    RT_ERR_UNSUPPORTED = -2,       /* spatial splits (--splits): SURVEY 8(f) rank 3, second half */
     RT_ERR_TOO_LARGE = -3,         /* n exceeds the 29-bit child index of Node (Common.cuh:152-159) */
     RT_ERR_HIP_BASE = -1000        /* -(hipError_t) + RT_ERR_HIP_BASE */
 };
@@ -130,6 +130,29 @@ size_t rt_nodes_bytes(uint32_t num_triangles);
  * leaf; leaf slots are assigned by a prefix sum in input order (the reference uses atomicAdd arrival order), the
  * leaf count L lands in scratch (rt_bu_scratch_layout.num_leaves); hybrid + pairs roots at (2L+1, 2). */
 int rt_run_bottom_up_build(const rt_build_input* input, const rt_arguments* args, int hybrid, void* stream);
+
+/* replaces SahMemoryRequirements (BuildWrapper.cu:126-130); about 90 bytes per triangle */
+size_t rt_sah_memory_requirements(uint32_t num_triangles);
+
+/* replaces RunSahBuild (BuildWrapper.cu:140-251), the reference's default --type: leaves bucketed into a 4x4x4 grid
+ * by centroid (Setup, GridBlockCounts/Scan/Distribute, Multiblock.cu:139-207,427-546), one binned-SAH sub-tree per
+ * cell and a SAH top tree over the cells (SharedTaskBuild, SharedTaskBuilder.cu:93-607,909-967).  Trace root =
+ * (slot 0, count 1) (main.cu:222-223).  input->scratch holds rt_sah_memory_requirements(n) bytes, nodes_out
+ * rt_nodes_bytes(n); the tree uses slots [0, 128 + 2L).  args->enable_pairs as in rt_run_bottom_up_build;
+ * args->enable_splits (SetupSplits / SetupPairSplits) -> RT_ERR_UNSUPPORTED.
+ * Same tree as the reference up to numbering, which is deterministic here: leaf slots in input order, node slots
+ * = f(split position) (see gpu-raytracing_amd/csrc/sah_build.hip).  The number of build levels is data dependent:
+ * like the reference (cudaMemcpy of num_leaves, BuildWrapper.cu:229) this call synchronises `stream`. */
+int rt_run_sah_build(const rt_build_input* input, const rt_arguments* args, void* stream);
+
+typedef struct rt_sah_scratch_layout {
+    size_t p_aabb, c_aabb;  /* int32[6] each: ordered-int primitive / centroid bounds of the scene (BuildWrapper.cu:170-176) */
+    size_t status;          /* uint32[8]: [0] error flags of the last build (0 = ok), [1] number of leaves L */
+    size_t num_leaves;      /* = status + 4 */
+    size_t cell_counts;     /* uint32[64]: leaves per grid cell (block_counts, Multiblock.cu:427) */
+    size_t total;
+} rt_sah_scratch_layout;
+int rt_sah_scratch_layout_get(uint32_t num_triangles, rt_sah_scratch_layout* out);
 
 /* Where the build's intermediates live inside `scratch` (for parity tests and callers that want the
  * sorted Morton codes).  Offsets in bytes. */

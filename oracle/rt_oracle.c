@@ -658,6 +658,290 @@ uint32_t ora_build_hybrid_top(ora_node* nodes, uint32_t L, const int32_t aabb[6]
     return K;
 }
 
+/* ================================================================== SAH path
+ * RunSahBuild (BuildWrapper.cu:140-251), splits off: Setup (Multiblock.cu:139-207) -> GridBlockCounts / GridBlockScan /
+ * GridBlockDistribute (:427-546): leaves bucketed by centroid into a 4 x 4 x 4 grid over the centroid bounds ->
+ * SharedTaskBuild per grid cell (SharedTaskBuilder.cu:93-607: top-down binned SAH, 8 bins on the longest centroid axis,
+ * leaf threshold 2, object-median split when the centroid box has no area) -> SharedTaskBuild(top_of_tree) over the
+ * non-empty cells.  Trace root = (slot 0, count 1) (main.cu:222-223).
+ *
+ * The reference numbers leaves, cell members, id order inside a partition and node slots by atomic arrival order
+ * (SURVEY 0.5); the tree it builds is the same up to that numbering.  DETERMINISTIC restatement, shared with the HIP
+ * kernels (gpu-raytracing_amd/csrc/sah_build.hip):
+ *   - leaf slot = input order (prefix sum of the per-candidate leaf counts with pairs on);
+ *   - cell members in ascending leaf index; non-empty cells in ascending cell index; partitions are stable;
+ *   - item positions: leaves occupy positions [0, L) of the id array (cell b = [start_b, end_b)), the top tree's
+ *     items (cells) positions [n, n+K) (n = number of input triangles >= L, known on the host with pairs on);
+ *   - node slots: the two child slots of a split between positions mid-1 | mid (or of a 2-item leaf group at
+ *     start, start+1 -> mid = start+1) sit at BIAS + 2*mid, BIAS = 128 for the cell trees and -2n for the top tree
+ *     (so the top tree lives in slots [0, 128), like the reference's 2*NUM_BLOCKS offset); the root descriptor of
+ *     cell b is slot 128 + 2*start_b (its sibling slot is unused, type None), the top root is slot 0.  Every slot
+ *     is written exactly once, independent of processing order.
+ * Box unions are taken on the ordered-int encoding everywhere (what the atomics do; differs from fminf only for
+ * -0 vs +0).  Two reference defects are not reproduced: a cell with ONE leaf has a Tri sub-root whose type the top
+ * tree overwrites with Box (SharedTaskBuilder.cu:432-446: garbage traversal) -- the type is copied here; and the
+ * grid cell index is clamped to [0, 3] (rounding of a merged pair's centre can leave the centroid bounds). */
+#define SAH_CELLS 64
+#define SAH_GRID 4
+typedef struct { int32_t v[6]; } ibox;   /* ordered-int box */
+static inline void ibox_reset(ibox* b) { b->v[0] = b->v[1] = b->v[2] = 0x7f7fffff; b->v[3] = b->v[4] = b->v[5] = (int32_t)0x80800000; }
+static inline void ibox_grow_box(ibox* b, const float* o)
+{
+    for (int k = 0; k < 3; k++) {
+        int32_t lo = ora_float_to_ordered_int(o[k]), hi = ora_float_to_ordered_int(o[3 + k]);
+        if (lo < b->v[k]) b->v[k] = lo;
+        if (hi > b->v[3 + k]) b->v[3 + k] = hi;
+    }
+}
+static inline void ibox_grow_pt(ibox* b, const float* c)
+{
+    for (int k = 0; k < 3; k++) {
+        int32_t q = ora_float_to_ordered_int(c[k]);
+        if (q < b->v[k]) b->v[k] = q;
+        if (q > b->v[3 + k]) b->v[3 + k] = q;
+    }
+}
+static inline void ibox_merge(ibox* b, const ibox* o)
+{
+    for (int k = 0; k < 3; k++) {
+        if (o->v[k] < b->v[k]) b->v[k] = o->v[k];
+        if (o->v[3 + k] > b->v[3 + k]) b->v[3 + k] = o->v[3 + k];
+    }
+}
+static inline void ibox_to_float(const ibox* b, float* f) { for (int k = 0; k < 6; k++) f[k] = ora_ordered_int_to_float(b->v[k]); }
+/* float -> int as the device converts it (cvt.rzi.s32.f32 / v_cvt_i32_f32): NaN -> 0, saturating */
+static inline int32_t cvt_rzi(float f)
+{
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return 2147483647;
+    if (f <= -2147483648.0f) return (int32_t)0x80000000;
+    return (int32_t)f;
+}
+static inline void box_centre(const float* b, float* c) { for (int k = 0; k < 3; k++) c[k] = (b[k] + b[3 + k]) * 0.5f; }
+
+typedef struct {
+    ora_node* nodes;
+    const float (*aabbs)[6];      /* item boxes: [0, L) leaves, [n, n+64) cells */
+    uint32_t* ids[2];             /* item ids per position (bit 31: the leaf holds two triangles) */
+    uint32_t L;                   /* here: n, the first cell item */
+    const uint32_t* cell_start;   /* top tree leaves point at the cell sub-roots */
+} sah_ctx;
+typedef struct { uint32_t start, end, parent_idx, buf; float c[6]; int has_c; } sah_task;
+
+static void sah_leaf_desc(const sah_ctx* x, ora_node* out, uint32_t idv)
+{
+    const uint32_t id = idv & 0x7FFFFFFFu;
+    if (id < x->L) {                                          /* (:405-421) leaf_type Tri */
+        put_node(out, x->aabbs[id], id, (idv >> 31) ? 2 : 1, ORA_TYPE_TRI);
+    } else {                                                  /* top_of_tree (:422-446): copy the cell's sub-root */
+        const ora_node* sub = &x->nodes[2 * SAH_CELLS + 2 * x->cell_start[id - x->L]];
+        put_node(out, x->aabbs[id], sub->w28 & NODE_PARENT_MASK, sub->w12 >> 29, sub->w28 >> 29);
+    }
+}
+
+/* one sub-tree: the task loop of SharedTaskBuild (:924-967) as a depth-first walk (slot numbering does not depend on
+ * the order).  c (centroid bounds) is given for root tasks, derived from the bins / halves for child tasks. */
+static void sah_build_range(const sah_ctx* x, sah_task root, int64_t bias)
+{
+    sah_task* stack = (sah_task*)malloc(sizeof(sah_task) * 64);
+    uint32_t cap = 64, sp = 0;
+    stack[sp++] = root;
+    while (sp) {
+        sah_task t = stack[--sp];
+        const uint32_t count = t.end - t.start;
+        const uint32_t* in = x->ids[t.buf];
+        uint32_t* out = x->ids[t.buf ^ 1];
+        /* the task's primitive box: union of its items (== Task::p_aabb: cell box / bin prefix boxes) */
+        ibox pi; ibox_reset(&pi);
+        ibox ci; ibox_reset(&ci);
+        for (uint32_t i = t.start; i < t.end; i++) {
+            const float* bx = x->aabbs[in[i] & 0x7FFFFFFFu];
+            float ctr[3]; box_centre(bx, ctr);
+            ibox_grow_box(&pi, bx);
+            ibox_grow_pt(&ci, ctr);
+        }
+        float pbox[6], cbox[6];
+        ibox_to_float(&pi, pbox);
+        if (t.has_c) memcpy(cbox, t.c, 24); else ibox_to_float(&ci, cbox);
+        if (count <= 2) {                                     /* (:396-464) LEAF_THRESHOLD 2 */
+            if (count == 1) { sah_leaf_desc(x, &x->nodes[t.parent_idx], in[t.start]); continue; }
+            const uint32_t child = (uint32_t)(bias + 2 * (int64_t)(t.start + 1));
+            for (uint32_t i = 0; i < count; i++) sah_leaf_desc(x, &x->nodes[child + i], in[t.start + i]);
+            put_node(&x->nodes[t.parent_idx], pbox, child, count, ORA_TYPE_BOX);
+            continue;
+        }
+        uint32_t mid = 0;
+        int done = 0;
+        if (!(box_sa(cbox) <= 0.0f)) {                        /* binned SAH (:206-350) */
+            const float lx = cbox[3] - cbox[0], ly = cbox[4] - cbox[1], lz = cbox[5] - cbox[2];
+            const int axis = 2 * (lz > lx && lz > ly) + 1 * (ly > lx && ly >= lz);
+            const float epsilon = 1.1920929e-7f;
+            const float k1 = 8 * (1 - epsilon) / (cbox[3 + axis] - cbox[axis]);
+            ibox bp[8];
+            uint32_t bn[8];
+            for (int b = 0; b < 8; b++) { ibox_reset(&bp[b]); bn[b] = 0; }
+            uint8_t* binof = (uint8_t*)malloc(count);
+            for (uint32_t i = t.start; i < t.end; i++) {
+                const float* bx = x->aabbs[in[i] & 0x7FFFFFFFu];
+                float ctr[3]; box_centre(bx, ctr);
+                int32_t bin = cvt_rzi(k1 * (ctr[axis] - cbox[axis]));
+                if (bin < 0) bin = 0;                         /* the reference reports an error and aborts the build */
+                if (bin > 7) bin = 7;
+                binof[i - t.start] = (uint8_t)bin;
+                ibox_grow_box(&bp[bin], bx);
+                bn[bin]++;
+            }
+            /* SelectPlane (:297-350): prefix left->right, sweep right->left, score = sa(L)*nL + sa(R)*nR, strict <,
+             * both sides non-empty, planes 6 -> 0 */
+            ibox lp[7];
+            uint32_t ln[7];
+            lp[0] = bp[0]; ln[0] = bn[0];
+            for (int i = 1; i < 7; i++) { lp[i] = lp[i - 1]; ibox_merge(&lp[i], &bp[i]); ln[i] = ln[i - 1] + bn[i]; }
+            ibox rp = bp[7];
+            uint32_t rn = bn[7];
+            float best = 3.402823466e+38f;
+            int plane = -1;
+            for (int i = 6; i >= 0; i--) {
+                float lf[6], rf[6];
+                ibox_to_float(&lp[i], lf); ibox_to_float(&rp, rf);
+                const float score = box_sa(lf) * ln[i] + box_sa(rf) * rn;
+                if (score < best && ln[i] && rn) { best = score; plane = i; }
+                ibox_merge(&rp, &bp[i]); rn += bn[i];
+            }
+            if (plane >= 0) {                                 /* PartitionIds (:352-380), stable here */
+                uint32_t w = t.start;
+                for (uint32_t i = t.start; i < t.end; i++) if (binof[i - t.start] <= plane) out[w++] = in[i];
+                mid = w;
+                for (uint32_t i = t.start; i < t.end; i++) if (binof[i - t.start] > plane) out[w++] = in[i];
+                done = 1;
+            }   /* else "failed to find valid partition" in the reference: falls through to the median split */
+            free(binof);
+        }
+        if (!done) {                                          /* object split at the midpoint (:465-510) */
+            mid = t.start + (count >> 1);
+            for (uint32_t i = t.start; i < t.end; i++) out[i] = in[i];
+        }
+        const uint32_t child_index = (uint32_t)(bias + 2 * (int64_t)mid);   /* (:544-606) */
+        put_node(&x->nodes[t.parent_idx], pbox, child_index, 2, ORA_TYPE_BOX);
+        sah_task l = {t.start, mid, child_index, t.buf ^ 1, {0}, 0};
+        sah_task r = {mid, t.end, child_index + 1, t.buf ^ 1, {0}, 0};
+        if (sp + 2 > cap) { cap *= 2; stack = (sah_task*)realloc(stack, sizeof(sah_task) * cap); }
+        stack[sp++] = r;
+        stack[sp++] = l;
+    }
+    free(stack);
+}
+
+uint32_t ora_build_sah(const ora_triangle* tris, uint32_t n, int enable_pairs, ora_node* nodes, ora_triangle_pair* leaves,
+                       uint32_t* cell_counts_out)
+{
+    /* ---- Setup (Multiblock.cu:139-207): leaves, their boxes, global primitive / centroid bounds */
+    float (*aabbs)[6] = (float (*)[6])malloc(((size_t)n + SAH_CELLS) * 24);
+    uint8_t* two = (uint8_t*)malloc((size_t)n + 1);
+    ibox gp, gc;
+    ibox_reset(&gp); ibox_reset(&gc);
+    uint32_t L = 0;
+    for (uint32_t tid = 0; tid < n; tid += 2) {
+        const int second_valid = tid + 1 < n;
+        const ora_triangle *a = &tris[tid], *b = second_valid ? &tris[tid + 1] : &tris[tid];
+        float ab[6], bb[6], pb[6], ac[3], bc[3];
+        tri_box(a, ab); tri_box(b, bb);
+        box_centre(ab, ac); box_centre(bb, bc);
+        for (int k = 0; k < 3; k++) { pb[k] = fminf(ab[k], bb[k]); pb[3 + k] = fmaxf(ab[3 + k], bb[3 + k]); }
+        ibox_grow_box(&gp, ab); ibox_grow_box(&gp, bb);          /* AtomicConvertCombine(*s_p_aabb, Combine(a, b)) */
+        ibox_grow_pt(&gc, ac); ibox_grow_pt(&gc, bc);            /* c_aabb = {min(a_c, b_c), max(a_c, b_c)} */
+        const int merge = enable_pairs && second_valid && pair_merges(tris, n, tid);
+        ora_triangle_pair r;
+        if (merge) {
+            memset(&r, 0, sizeof r);
+            int ra = 0, rb = 0;
+            can_form_pair(a, b, &ra, &rb);
+            ora_triangle ar = *a;                                /* RotateTriangle (Pairing.cuh:9-21) */
+            if (ra == 1) { ar.v0 = a->v2; ar.v1 = a->v0; ar.v2 = a->v1; }
+            else if (ra == 2) { ar.v0 = a->v1; ar.v1 = a->v2; ar.v2 = a->v0; }
+            r.v0 = ar.v0; r.v1 = ar.v1; r.v2 = ar.v2;
+            r.v3 = rb == 2 ? b->v0 : rb == 1 ? b->v1 : b->v2;
+            r.primitive_id_0 = tid; r.primitive_id_1 = tid + 1;
+            r.rot_x = (uint16_t)ra; r.rot_y = (uint16_t)rb;
+            leaves[L] = r;
+            /* the union on the ordered-int encoding, like every other box of this path */
+            ibox u; ibox_reset(&u); ibox_grow_box(&u, ab); ibox_grow_box(&u, bb); ibox_to_float(&u, aabbs[L]);
+            (void)pb;
+            two[L] = 1;
+            L++;
+        } else {
+            for (int s = 0; s < 1 + second_valid; s++) {
+                const ora_triangle* t = s ? b : a;
+                memset(&r, 0, sizeof r);
+                r.v0 = t->v0; r.v1 = t->v1; r.v2 = t->v2; r.v3 = t->v2;
+                r.primitive_id_0 = tid + s;
+                leaves[L] = r;
+                memcpy(aabbs[L], s ? bb : ab, 24);
+                two[L] = 0;
+                L++;
+            }
+        }
+    }
+    /* every slot this build can leave unwritten is defined as type None */
+    memset(nodes, 0, sizeof(ora_node) * ((size_t)2 * SAH_CELLS + 2 * (size_t)L + 2));
+    uint32_t cell_count[SAH_CELLS] = {0}, cell_start[SAH_CELLS];
+    if (L == 0) { free(aabbs); free(two); if (cell_counts_out) memcpy(cell_counts_out, cell_count, sizeof cell_count); return 0; }
+
+    /* ---- GridBlockCounts / Scan / Distribute (:427-546) */
+    float gcf[6], gpf[6];
+    ibox_to_float(&gc, gcf); ibox_to_float(&gp, gpf);
+    const float epsilon = 1.1920929e-7f;
+    const float gscale = SAH_GRID * (1 - epsilon);
+    uint8_t* cell_of = (uint8_t*)malloc(L);
+    ibox cell_p[SAH_CELLS], cell_c[SAH_CELLS];
+    for (int b = 0; b < SAH_CELLS; b++) { ibox_reset(&cell_p[b]); ibox_reset(&cell_c[b]); }
+    for (uint32_t i = 0; i < L; i++) {
+        float ctr[3]; box_centre(aabbs[i], ctr);
+        int32_t q[3];
+        for (int k = 0; k < 3; k++) {
+            q[k] = cvt_rzi((ctr[k] - gcf[k]) * gscale / (gcf[3 + k] - gcf[k]));
+            if (q[k] < 0) q[k] = 0;
+            if (q[k] > SAH_GRID - 1) q[k] = SAH_GRID - 1;
+        }
+        const int cell = q[0] + q[1] * SAH_GRID + q[2] * SAH_GRID * SAH_GRID;
+        cell_of[i] = (uint8_t)cell;
+        cell_count[cell]++;
+        ibox_grow_box(&cell_p[cell], aabbs[i]);
+        ibox_grow_pt(&cell_c[cell], ctr);
+    }
+    uint32_t run = 0;
+    for (int b = 0; b < SAH_CELLS; b++) { cell_start[b] = run; run += cell_count[b]; }
+    if (cell_counts_out) memcpy(cell_counts_out, cell_count, sizeof cell_count);
+    uint32_t* ids0 = (uint32_t*)malloc(((size_t)n + SAH_CELLS) * 4);
+    uint32_t* ids1 = (uint32_t*)malloc(((size_t)n + SAH_CELLS) * 4);
+    {
+        uint32_t cur[SAH_CELLS];
+        memcpy(cur, cell_start, sizeof cur);
+        for (uint32_t i = 0; i < L; i++) ids0[cur[cell_of[i]]++] = i | (two[i] ? 0x80000000u : 0u);
+    }
+    uint32_t K = 0;
+    for (int b = 0; b < SAH_CELLS; b++) {
+        ibox_to_float(&cell_p[b], aabbs[n + b]);
+        if (cell_count[b]) ids0[n + K++] = n + (uint32_t)b;
+    }
+    sah_ctx x = {nodes, (const float (*)[6])aabbs, {ids0, ids1}, n, cell_start};
+    /* ---- SharedTaskBuild per cell: root descriptor at 2*64 + 2*start_b (SharedTaskBuilder.cu:116-127) */
+    for (int b = 0; b < SAH_CELLS; b++) {
+        if (!cell_count[b]) continue;
+        sah_task t = {cell_start[b], cell_start[b] + cell_count[b], 2 * SAH_CELLS + 2 * cell_start[b], 0, {0}, 1};
+        ibox_to_float(&cell_c[b], t.c);
+        sah_build_range(&x, t, 2 * SAH_CELLS);
+    }
+    /* ---- SharedTaskBuild(top_of_tree): items = non-empty cells, c / p = the global bounds, root descriptor slot 0 */
+    {
+        sah_task t = {n, n + K, 0, 0, {0}, 1};
+        memcpy(t.c, gcf, 24);
+        sah_build_range(&x, t, -2 * (int64_t)n);
+    }
+    free(aabbs); free(two); free(cell_of); free(ids0); free(ids1);
+    return L;
+}
+
 /* ------------------------------------------------------------------ Utilities.cpp:8-44
  * (recursion restated with an explicit stack so deep trees cannot overflow the C stack) */
 void ora_count_nodes(const ora_node* nodes, uint32_t root, uint32_t count, int32_t out[3])

@@ -131,6 +131,13 @@ uint32_t ora_build_pairs(const ora_triangle* tris, uint32_t n, ora_node* nodes, 
  * subroots_out (may be NULL): the sub-root pair indices in emission order. */
 uint32_t ora_build_hybrid_top(ora_node* nodes, uint32_t L, const int32_t aabb_ordered[6], uint32_t* subroots_out);
 
+/* SAH path: RunSahBuild (BuildWrapper.cu:140-251) without spatial splits, restated
+ * deterministically -- see the comment above ora_build_sah in rt_oracle.c for the numbering rules.  nodes must hold
+ * 2*64 + 2*n + 2 slots (the reference allocates 4*(n+512), main.cu:235-237), leaves n entries.  Trace root =
+ * (slot 0, count 1).  cell_counts_out (may be NULL): leaves per grid cell [64].  Returns the number of leaves L. */
+uint32_t ora_build_sah(const ora_triangle* tris, uint32_t n, int enable_pairs, ora_node* nodes, ora_triangle_pair* leaves,
+                       uint32_t* cell_counts_out);
+
 /* Utilities.cpp:8-44 : out[3] = {numNodes, numLeafNodes, numTreeNodes} */
 void ora_count_nodes(const ora_node* nodes, uint32_t root, uint32_t count, int32_t out[3]);
 /* Utilities.cpp:46-83 : returns the number of failing Box slots (reference prints one line each) */
