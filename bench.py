@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--camera", choices=["a", "b"], default="a")
     ap.add_argument("--render-type", type=int, default=0)
     ap.add_argument("--build-reps", type=int, default=10)
+    ap.add_argument("--type", choices=["bottom-up", "sah", "sah-pairs"], default="bottom-up",
+                    help="tree the rays are traced through: the LBVH of the headline metric (default) or the SAH tree "
+                         "(rt_run_sah_build, the reference's default --type; reported as a separate workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the build timing")
     ap.add_argument("--other-camera", action="store_true",
@@ -87,13 +90,22 @@ def main():
     G, W, H = args.grid, args.width, args.height
     tris = scenes.grid_mesh(G, 1)
     n = tris.shape[0]
-    inp = rt.BuildInput.allocate(tris)
+    sah = args.type != "bottom-up"
+    inp = rt.BuildInput.allocate(tris, sah=sah)
+    sah_args = rt.Arguments(build_type=rt.kSAH, enable_pairs=args.type == "sah-pairs")
+    ROOT_IDX, ROOT_CNT = (0, 1) if sah else (0, 2)      # main.cu:222-223
+
+    def build():
+        if sah:
+            rt.RunSahBuild(inp, sah_args)
+        else:
+            rt.RunBottomUpBuild(inp)
 
     def ev():
         return torch.cuda.Event(enable_timing=True)
 
     # ---- build (replicated on every rank); timed with events on the launch stream, scratch preallocated
-    rt.RunBottomUpBuild(inp)
+    build()
     torch.cuda.synchronize()
     build_ms = None
     if not args.no_extras:
@@ -101,7 +113,7 @@ def main():
         for _ in range(args.build_reps):
             e0, e1 = ev(), ev()
             e0.record()
-            rt.RunBottomUpBuild(inp)
+            build()
             e1.record()
             e1.synchronize()
             times.append(e0.elapsed_time(e1))
@@ -129,7 +141,7 @@ def main():
             pending[k] = None
         if events is not None:
             events[0].record()
-        rt.Trace(inp.triangles_out, inp.nodes_out, frames[k], (W, H), cam_dev[cam_key], 0, 2,
+        rt.Trace(inp.triangles_out, inp.nodes_out, frames[k], (W, H), cam_dev[cam_key], ROOT_IDX, ROOT_CNT,
                  render_type=args.render_type, counters=counters if with_counters else None,
                  rows=(y0, y1), spp=args.spp)
         if events is not None:
@@ -184,7 +196,7 @@ def main():
 
     # local (this rank's band) algorithmic bytes for the roofline of the trace kernel:
     counters.zero_()
-    rt.Trace(inp.triangles_out, inp.nodes_out, frame, (W, H), cam_dev[cam], 0, 2, render_type=args.render_type,
+    rt.Trace(inp.triangles_out, inp.nodes_out, frame, (W, H), cam_dev[cam], ROOT_IDX, ROOT_CNT, render_type=args.render_type,
              counters=counters, rows=(y0, y1), spp=args.spp)
     torch.cuda.synchronize()
     lbox, ltri = int(counters[0].item()), int(counters[1].item())
@@ -197,6 +209,22 @@ def main():
             "build_ms": round(build_ms, 4),
             "build_gbps_algorithmic": round(512.0 * n / (build_ms * 1e-3) / 1e9, 1),  # 512 B/triangle, SURVEY 8(d)
         }
+    if not args.no_extras and not sah and world == 1:
+        # the SAH builder (the reference's default --type) on the same triangles: build time only here, so that every
+        # trace_kernel launch of the default command stays the headline workload; `--type sah` traces through it
+        sinp = rt.BuildInput.allocate(tris, sah=True)
+        rt.RunSahBuild(sinp)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            e0, e1 = ev(), ev()
+            e0.record()
+            rt.RunSahBuild(sinp)
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        extras["sah_build_ms"] = round(statistics.median(ts), 4)
+        del sinp
     if args.other_camera:
         other = "b" if cam == "a" else "a"
         obox, otri, _, _ = test_counts(other)
@@ -219,7 +247,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"grid_mesh(G={G}, seed=1) = {n} triangles, {W}x{H}, {args.spp} spp, camera "
                                    f"{cam.upper()} ({'top-down' if cam == 'a' else 'oblique'}), render_type {args.render_type}; "
-                                   "LBVH replicated per GPU",
+                                   + ("LBVH" if not sah else "SAH tree" + (" with triangle pairs" if args.type == "sah-pairs" else ""))
+                                   + " replicated per GPU",
                        "parallelism": f"row-bands x{world}" + (" + RCCL gather to rank 0, double-buffered frames" if world > 1 else "")},
             "box_tests_per_ray": round(box / rays, 2), "tri_tests_per_ray": round(tri / rays, 3),
             "wave_steps": {"box_phase": wsteps_box, "leaf_phase": wsteps_leaf,
@@ -233,14 +262,14 @@ def main():
         }
         out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(tris, cams[cam], W, H, args.spp, args.render_type, G)
+            out["cpu_baseline"] = cpu_baseline(tris, cams[cam], W, H, args.spp, args.render_type, G, args.type)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(tris, cam, W, H, spp, render_type, G):
+def cpu_baseline(tris, cam, W, H, spp, render_type, G, tree="bottom-up"):
     """The oracle (C port of the reference algorithm, OpenMP) timed on this box's host cores on ONE frame of the
     same workload.  Reported baseline only."""
     from oracle import oracle_py as ora
@@ -257,14 +286,14 @@ def cpu_baseline(tris, cam, W, H, spp, render_type, G):
         pass
     ora.set_threads(cores)
     t0 = time.perf_counter()
-    o = ora.build_bvh(tris)
+    o = ora.build_bvh(tris) if tree == "bottom-up" else ora.build_sah(tris, tree == "sah-pairs")
     t_build = time.perf_counter() - t0
     t0 = time.perf_counter()
-    ora.trace(o["leaves"], o["nodes"], 0, 2, cam, W, H, render_type=render_type, spp=spp)
+    ora.trace(o["leaves"], o["nodes"], o.get("root", 0), o.get("count", 2), cam, W, H, render_type=render_type, spp=spp)
     t_trace = time.perf_counter() - t0
     return {"value": round(W * H * spp / t_trace / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": f"1 full {W}x{H} frame ({spp} spp) of the same scene and camera, oracle/liboracle.so "
-                      f"(-O2 -ffp-contract=off, OpenMP over rows); LBVH build of the same {tris.shape[0]} triangles",
+                      f"(-O2 -ffp-contract=off, OpenMP over rows); {'LBVH' if tree == 'bottom-up' else 'SAH'} build (single thread) of the same {tris.shape[0]} triangles",
             "build_ms": round(t_build * 1e3, 1), "trace_s": round(t_trace, 3)}
 
 

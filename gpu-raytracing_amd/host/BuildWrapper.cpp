@@ -19,5 +19,12 @@ void RunBottomUpBuild(BuildInput input, Arguments args, bool hybrid, void* strea
     if (rc != RT_OK) Die("RunBottomUpBuild", rc);
 }
 
-size_t SahMemoryRequirements(uint32_t) { return 0; }
-void RunSahBuild(BuildInput, Arguments) { Die("RunSahBuild", RT_ERR_UNSUPPORTED); }
+size_t SahMemoryRequirements(uint32_t num_triangles) { return rt_sah_memory_requirements(num_triangles); }
+
+void RunSahBuild(BuildInput input, Arguments args, void* stream)
+{
+    rt_build_input in{input.triangles_in, input.triangles_out, input.num_triangles, input.nodes_out, input.scratch};
+    rt_arguments a{(int32_t)args.build_type, args.enable_splits ? 1 : 0, args.enable_pairs ? 1 : 0, (int32_t)args.render_type};
+    const int rc = rt_run_sah_build(&in, &a, stream);
+    if (rc != RT_OK) Die("RunSahBuild", rc);
+}

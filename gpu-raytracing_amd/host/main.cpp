@@ -1,7 +1,7 @@
 // main.cpp -- headless counterpart of the reference's main.cu: what Display() does at frame 0 (main.cu:215-265)
 // plus one Trace() (main.cu:125-192), with the frame written as a PPM instead of shown in a GL window.
 //
-//   rt_cli <file.obj> [--type bottom-up|hybrid] [--pairs] [--splits] [--render depth|boxtests|tritests|material|lods|diffuse|texture|texturelit|shadows]
+//   rt_cli <file.obj> [--type sah|bottom-up|hybrid] [--pairs] [--splits] [--render depth|boxtests|tritests|material|lods|diffuse|texture|texturelit|shadows]
 //          [--width W] [--height H] [--spp N] [--yaw Y --pitch P --pos X Y Z] [--out frame.ppm] [--frames K]
 #include <chrono>
 #include <cstdio>
@@ -35,12 +35,11 @@ static RenderType ParseRender(const std::string& s)
 int main(int argc, char** argv)
 {
     if (argc < 2) {
-        fprintf(stderr, "usage: %s <file.obj> [--type bottom-up|hybrid] [--render depth|boxtests|tritests|material|lods|diffuse|texture|texturelit|shadows] "
+        fprintf(stderr, "usage: %s <file.obj> [--type sah|bottom-up|hybrid] [--render depth|boxtests|tritests|material|lods|diffuse|texture|texturelit|shadows] "
                         "[--width W] [--height H] [--spp N] [--yaw Y] [--pitch P] [--pos X Y Z] [--out f.ppm] [--frames K]\n", argv[0]);
         return 2;
     }
     Arguments args = ParseCmd(argc, argv);
-    if (args.build_type == kSAH) args.build_type = kBottomUp;  // the SAH builder is not part of this build
     int width = 1024, height = 768, frames = 1;                 // the reference's window size (main.cu:44-45)
     unsigned spp = 1;
     std::string out;
@@ -63,8 +62,8 @@ int main(int argc, char** argv)
 
     Scene scene = LoadOBJFromFile(g_filename);
     const unsigned n = (unsigned)scene.triangles.size();
-    const bool hybrid = args.build_type == kHybrid;
-    const unsigned root_count = 2;                        // main.cu:223 (bottom-up / hybrid)
+    const bool hybrid = args.build_type == kHybrid, sah = args.build_type == kSAH;
+    const unsigned root_count = sah ? 1 : 2;              // main.cu:223
 
     MemoryBuffer<Camera> camera(1);
     memset(camera.data(), 0, sizeof(Camera));
@@ -80,7 +79,7 @@ int main(int argc, char** argv)
     in.num_triangles = n;
     check(hipMalloc((void**)&in.triangles_in, sizeof(Triangle) * (n ? n : 1)));
     check(hipMalloc((void**)&in.triangles_out, sizeof(TrianglePair) * (size_t)(n ? n : 1) * 2));
-    check(hipMalloc(&in.scratch, BuMemoryRequirements(n)));
+    check(hipMalloc(&in.scratch, sah ? SahMemoryRequirements(n) : BuMemoryRequirements(n)));   // main.cu:227-234
     check(hipMalloc((void**)&in.nodes_out, rt_nodes_bytes(n)));
     if (n) check(hipMemcpy(in.triangles_in, scene.triangles.data(), sizeof(Triangle) * n, hipMemcpyHostToDevice));
 
@@ -88,18 +87,19 @@ int main(int argc, char** argv)
     check(hipEventCreate(&e0));
     check(hipEventCreate(&e1));
     check(hipEventRecord(e0, nullptr));
-    RunBottomUpBuild(in, args, hybrid);
+    if (sah) RunSahBuild(in, args); else RunBottomUpBuild(in, args, hybrid);   // main.cu:242-246
     check(hipEventRecord(e1, nullptr));
     check(hipEventSynchronize(e1));
     float build_ms = 0;
     check(hipEventElapsedTime(&build_ms, e0, e1));
-    printf("RunBottomUpBuild time elapsed: %fms\n", build_ms);
+    printf("%s time elapsed: %fms\n", sah ? "RunSahBuild" : "RunBottomUpBuild", build_ms);
     // number of leaves L: n, unless --pairs merged triangles.  The reference roots a hybrid tree at 2n+1 even then
     // (main.cu:222); the top tree is written at 2L, so the root is 2L+1.
-    rt_bu_scratch_layout lay;
-    rt_bu_scratch_layout_get(n, &lay);
+    size_t num_leaves_off;
+    if (sah) { rt_sah_scratch_layout lay; rt_sah_scratch_layout_get(n, &lay); num_leaves_off = lay.num_leaves; }
+    else { rt_bu_scratch_layout lay; rt_bu_scratch_layout_get(n, &lay); num_leaves_off = lay.num_leaves; }
     unsigned num_leaves = n;
-    check(hipMemcpy(&num_leaves, static_cast<char*>(in.scratch) + lay.num_leaves, 4, hipMemcpyDeviceToHost));
+    check(hipMemcpy(&num_leaves, static_cast<char*>(in.scratch) + num_leaves_off, 4, hipMemcpyDeviceToHost));
     const unsigned root_index = hybrid ? (num_leaves * 2 > 2 ? num_leaves * 2 : 2) + 1 : 0;
     if (args.enable_pairs) printf("  leaves after pairing: %u of %u triangles\n", num_leaves, n);
 

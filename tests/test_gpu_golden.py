@@ -56,7 +56,7 @@ def test_gpu_matches_golden(name, golden, fixtures):
         assert (np.load(os.path.join(GOLD, "cornell34_frame_r0.npz"))["rgba"] == gpu_trace(b, cam, w, h, 0)[0]).all()
 
 
-@pytest.mark.parametrize("build_type", ["bottom-up", "hybrid"])
+@pytest.mark.parametrize("build_type", ["bottom-up", "hybrid", "sah"])
 def test_rt_cli_end_to_end(tmp_path, rt, ora, build_type):
     """The C++ host path the reference's main() takes: LoadOBJFromFile -> InitialiseCamera -> RunBottomUpBuild ->
     CountNodes / VerifyHierarchy -> Trace, through gpu-raytracing_amd/host/rt_cli, checked against the oracle."""
@@ -76,8 +76,10 @@ def test_rt_cli_end_to_end(tmp_path, rt, ora, build_type):
     cam = host.InitialiseCamera(s["aabb"])
     cam["position"], cam["yaw"], cam["pitch"] = [5, 5, -5.25], 0, 0
     cam = host.UpdateCamera(cam)
-    o = ora.build_bvh(s["triangles"]) if build_type == "bottom-up" else ora.build_hybrid(s["triangles"])
-    exp, cnt = ora.trace(o["leaves"], o["nodes"], o.get("root", 0), 2, cam, 320, 200, render_type=5, attributes=s["attributes"],
+    if build_type == "sah":
+        assert "num nodes: 67" in p.stdout and "RunSahBuild time elapsed" in p.stdout
+    o = {"bottom-up": ora.build_bvh, "hybrid": ora.build_hybrid, "sah": ora.build_sah}[build_type](s["triangles"])
+    exp, cnt = ora.trace(o["leaves"], o["nodes"], o.get("root", 0), o.get("count", 2), cam, 320, 200, render_type=5, attributes=s["attributes"],
                          materials=s["materials"], light=tuple(s["light"]))
     assert int(re.search(r"TraceRays number of tests (\d+)", p.stdout).group(1)) == int(cnt[0])
     raw = open(out, "rb").read()
