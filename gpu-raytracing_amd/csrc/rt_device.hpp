@@ -33,23 +33,38 @@ __device__ __forceinline__ float ordered_int_to_float(int i)
 // ---- wave64 helpers
 __device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
+// wave-wide reductions: four DPP steps reduce each row of 16 lanes (quad swaps, half-row mirror, row mirror: VALU
+// only, no LDS-crossbar permutes), v_readlane picks one lane per row and the scalar unit combines the four rows.
+// The result is wave-uniform.  All 64 lanes must be active at the call.
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
 __device__ __forceinline__ int wave_min_i32(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-    return v;
+    v = min(v, dpp_mov<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = min(v, dpp_mov<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = min(v, dpp_mov<0x141>(v));   // row_half_mirror
+    v = min(v, dpp_mov<0x140>(v));   // row_mirror
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 __device__ __forceinline__ int wave_max_i32(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
-    return v;
+    v = max(v, dpp_mov<0xB1>(v));
+    v = max(v, dpp_mov<0x4E>(v));
+    v = max(v, dpp_mov<0x141>(v));
+    v = max(v, dpp_mov<0x140>(v));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    int s = (int)v;
+    s += dpp_mov<0xB1>(s);
+    s += dpp_mov<0x4E>(s);
+    s += dpp_mov<0x141>(s);
+    s += dpp_mov<0x140>(s);
+    return (uint32_t)(__builtin_amdgcn_readlane(s, 0) + __builtin_amdgcn_readlane(s, 16) +
+                      __builtin_amdgcn_readlane(s, 32) + __builtin_amdgcn_readlane(s, 48));
 }
 // inclusive scan across the 64 lanes of a wave
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)

@@ -12,11 +12,12 @@
 //     here every task of every cell that is alive in a level is processed in the same launch:
 //       sah_bin_kernel       256 positions per workgroup; bins are aggregated in LDS per (task, bin) and flushed with
 //                            a handful of integer atomics (ordered-int min / max / add: order independent);
-//       sah_split_kernel     one wave per task: plane selection, parent descriptor, child tasks, and the per-chunk
-//                            prefix of "goes left" counts a task spanning several workgroups needs;
+//       sah_split_kernel     one thread per task: plane selection, parent descriptor, child tasks; the whole wave
+//                            helps with what scales with a task's size (median child boxes, the per-chunk prefix
+//                            of "goes left" counts a task spanning several workgroups needs);
 //       sah_partition_kernel stable partition (block scan + that prefix) into the other id buffer;
-//     tasks of <= 32 items leave the level loop and are finished by sah_small_kernel, one thread per task
-//     (the reference's PerInstanceRunTask, SharedTaskBuilder.cu:742-907);
+//     tasks of <= 64 items leave the level loop and are finished by sah_small_kernel, one wave per task
+//     (the reference runs its small tasks one thread each: PerInstanceRunTask, SharedTaskBuilder.cu:742-907);
 //   * node slots are a function of the split POSITION (slot = bias + 2 * mid), not of an allocation counter, so no
 //     kernel needs to agree on an order and the top tree is built in the same launches as the cell trees;
 //   * leaf slots = input order (pairs: prefix sums), cell members by one stable 8-bit radix pass (radix_sort.hip).
@@ -31,8 +32,8 @@ namespace rt {
 
 constexpr uint32_t kSahCells = 64;
 constexpr uint32_t kSahChunk = 256;       // positions per workgroup in the level kernels
-constexpr uint32_t kSahSmall = 32;        // tasks with <= 32 items are finished by one thread
-constexpr uint32_t kSahMaxLocal = 32;     // runs of equal task id a chunk can hold (tasks in the loop have >= 33 items)
+constexpr uint32_t kSahSmall = 64;        // tasks with <= 64 items are finished by one wave
+constexpr uint32_t kSahMaxLocal = 32;     // runs of equal task id a chunk can hold (tasks in the loop have >= 65 items)
 constexpr uint32_t kInactive = 0xFFFFFFFFu;
 constexpr uint32_t kSahMaxLevels = 1024;
 constexpr int kEmptyLo = 0x7f7fffff, kEmptyHi = (int)0x80800000;   // ordered-int FLT_MAX / -FLT_MAX (BuildWrapper.cu:170-171)
@@ -144,22 +145,27 @@ __global__ __launch_bounds__(256) void sah_setup_kernel(const float* __restrict_
     __shared__ int sb[12];
     __shared__ uint32_t ws[8];
     if (threadIdx.x < 12) sb[threadIdx.x] = (threadIdx.x % 6) < 3 ? kEmptyLo : kEmptyHi;
-    const uint32_t k = blockIdx.x * 256 + threadIdx.x, tid = 2 * k;
+    __syncthreads();
+    // a bounded number of workgroups walks the tiles: the scene bounds end in 12 same-address global atomics per
+    // workgroup, and those serialise across the 8 L2s (about 50 ns each)
+    const uint32_t ntiles = ((n + 1) / 2 + 255) / 256;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const uint32_t k = tile * 256 + threadIdx.x, tid = 2 * k;
     const bool live = tid < n, second = tid + 1 < n;
     const bool merge = live && flags && flags[k] != 0;
     const uint32_t valid = live ? 1u + ((second && !merge) ? 1u : 0u) : 0u;
     uint32_t slot = tid;
     if (flags) {
         uint32_t total;
-        slot = block_offsets[blockIdx.x] + block_excl_scan_u32<256>(valid, ws, &total);
-    } else {
-        __syncthreads();
+        slot = block_offsets[tile] + block_excl_scan_u32<256>(valid, ws, &total);
     }
+    int bnd[12];   // this candidate's contribution to the scene bounds (identity when not live)
+#pragma unroll
+    for (int j = 0; j < 12; j++) bnd[j] = (j % 6) < 3 ? kEmptyLo : kEmptyHi;
+    float A[9], B[9], ab[6], bb[6];
     if (live) {
-        float A[9], B[9];
         load_tri9(f + (size_t)tid * 9, A);
         load_tri9(f + (size_t)(second ? tid + 1 : tid) * 9, B);
-        float ab[6], bb[6];
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             ab[j] = fminf(fminf(A[j], A[3 + j]), A[6 + j]); ab[3 + j] = fmaxf(fmaxf(A[j], A[3 + j]), A[6 + j]);
@@ -168,11 +174,19 @@ __global__ __launch_bounds__(256) void sah_setup_kernel(const float* __restrict_
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             const float ac = (ab[j] + ab[3 + j]) * 0.5f, bc = (bb[j] + bb[3 + j]) * 0.5f;
-            atomicMin(&sb[j], min(float_to_ordered_int(ab[j]), float_to_ordered_int(bb[j])));
-            atomicMax(&sb[3 + j], max(float_to_ordered_int(ab[3 + j]), float_to_ordered_int(bb[3 + j])));
-            atomicMin(&sb[6 + j], min(float_to_ordered_int(ac), float_to_ordered_int(bc)));
-            atomicMax(&sb[9 + j], max(float_to_ordered_int(ac), float_to_ordered_int(bc)));
+            bnd[j] = min(float_to_ordered_int(ab[j]), float_to_ordered_int(bb[j]));
+            bnd[3 + j] = max(float_to_ordered_int(ab[3 + j]), float_to_ordered_int(bb[3 + j]));
+            bnd[6 + j] = min(float_to_ordered_int(ac), float_to_ordered_int(bc));
+            bnd[9 + j] = max(float_to_ordered_int(ac), float_to_ordered_int(bc));
         }
+    }
+    // one LDS atomic per wave and value instead of 64 on the same address
+#pragma unroll
+    for (int j = 0; j < 12; j++) {
+        const int r = (j % 6) < 3 ? wave_min_i32(bnd[j]) : wave_max_i32(bnd[j]);
+        if ((threadIdx.x & 63) == 0) { if ((j % 6) < 3) atomicMin(&sb[j], r); else atomicMax(&sb[j], r); }
+    }
+    if (live) {
         uint4* out = reinterpret_cast<uint4*>(leaves + slot);
         float2* bo = reinterpret_cast<float2*>(aabbs + (size_t)slot * 6);
         if (merge) {
@@ -213,6 +227,7 @@ __global__ __launch_bounds__(256) void sah_setup_kernel(const float* __restrict_
             }
         }
     }
+    }   // tiles
     __syncthreads();
     if (threadIdx.x < 12) {
         int* g = threadIdx.x < 6 ? &H->gp[threadIdx.x] : &H->gc[threadIdx.x - 6];
@@ -234,7 +249,14 @@ __global__ __launch_bounds__(256) void sah_grid_kernel(const float* __restrict__
     }
     if (threadIdx.x < kSahCells) cnt[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    float glo[3], ghi[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { glo[k] = ordered_int_to_float(H->gc[k]); ghi[k] = ordered_int_to_float(H->gc[3 + k]); }
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < ((L + 255) & ~255u); i += gridDim.x * 256) {
+    int cell = -1;
+    int v[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) v[k] = (k % 6) < 3 ? kEmptyLo : kEmptyHi;
     if (i < L) {
         float b[6];
         load_box(aabbs, i, b);
@@ -243,22 +265,41 @@ __global__ __launch_bounds__(256) void sah_grid_kernel(const float* __restrict__
         int q[3];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            const float lo = ordered_int_to_float(H->gc[k]), hi = ordered_int_to_float(H->gc[3 + k]);
             const float ctr = (b[k] + b[3 + k]) * 0.5f;
-            q[k] = min(3, max(0, cvt_rzi((ctr - lo) * gscale / (hi - lo))));
+            q[k] = min(3, max(0, cvt_rzi((ctr - glo[k]) * gscale / (ghi[k] - glo[k]))));
         }
-        const int cell = q[0] + q[1] * 4 + q[2] * 16;
+        cell = q[0] + q[1] * 4 + q[2] * 16;
         keys[i] = (uint32_t)cell;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            const float ctr = (b[k] + b[3 + k]) * 0.5f;
-            atomicMin(&cp[cell][k], float_to_ordered_int(b[k]));
-            atomicMax(&cp[cell][3 + k], float_to_ordered_int(b[3 + k]));
-            atomicMin(&cc[cell][k], float_to_ordered_int(ctr));
-            atomicMax(&cc[cell][3 + k], float_to_ordered_int(ctr));
+            const int ctr = float_to_ordered_int((b[k] + b[3 + k]) * 0.5f);
+            v[k] = float_to_ordered_int(b[k]); v[3 + k] = float_to_ordered_int(b[3 + k]);
+            v[6 + k] = ctr; v[9 + k] = ctr;
+        }
+    }
+    // consecutive leaves mostly share a cell: when the whole wave agrees, reduce in registers and touch LDS once
+    const int c0 = __builtin_amdgcn_readfirstlane(cell);
+    if (c0 >= 0 && __builtin_amdgcn_ballot_w64(cell == c0) == ~0ull) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const int r = (k % 6) < 3 ? wave_min_i32(v[k]) : wave_max_i32(v[k]);
+            if ((threadIdx.x & 63) == 0) {
+                int* dst = k < 6 ? &cp[c0][k] : &cc[c0][k - 6];
+                if ((k % 6) < 3) atomicMin(dst, r); else atomicMax(dst, r);
+            }
+        }
+        if ((threadIdx.x & 63) == 0) atomicAdd(&cnt[c0], 64u);
+    } else if (cell >= 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            atomicMin(&cp[cell][k], v[k]);
+            atomicMax(&cp[cell][3 + k], v[3 + k]);
+            atomicMin(&cc[cell][k], v[6 + k]);
+            atomicMax(&cc[cell][3 + k], v[9 + k]);
         }
         atomicAdd(&cnt[cell], 1u);
     }
+    }   // tiles
     __syncthreads();
     if (threadIdx.x < kSahCells && cnt[threadIdx.x]) {
         const uint32_t c = threadIdx.x;
@@ -409,7 +450,19 @@ __global__ __launch_bounds__(256) void sah_bin_kernel(SahArgs a, uint32_t lvl)
     __syncthreads();
     {
         const uint32_t l = threadIdx.x >> 3, bin = threadIdx.x & 7;
-        if (l < nloc && lbins[l][bin][12] > 0) {
+        // a task that lies inside this chunk (not the first run continuing from the left, not the last run
+        // continuing to the right) owns its bins: plain stores, no atomics
+        const uint32_t tl = l < nloc ? ltask[l] : kInactive;
+        bool inside = false;
+        if (tl != kInactive) {
+            const SahTask* T = &a.tasks[cur][tl];
+            inside = T->start >= chunk * kSahChunk && T->end <= (chunk + 1) * kSahChunk;
+        }
+        if (inside) {
+            int* g = a.bins[cur] + ((size_t)tl * 8 + bin) * kBinWords;
+#pragma unroll
+            for (int k = 0; k < (int)kBinWords; k++) g[k] = lbins[l][bin][k];
+        } else if (tl != kInactive && lbins[l][bin][12] > 0) {
             int* g = a.bins[cur] + ((size_t)ltask[l] * 8 + bin) * kBinWords;
             const int* s = &lbins[l][bin][0];
 #pragma unroll
@@ -436,141 +489,169 @@ __device__ __forceinline__ void ibox_to_float(const int* b, float* f)
     for (int k = 0; k < 6; k++) f[k] = ordered_int_to_float(b[k]);
 }
 
-// SelectPlane (SharedTaskBuilder.cu:297-350) on 8 bins of 13 ints.  Returns the plane (or -1) and the child boxes.
-__device__ __forceinline__ int sah_select_plane(const int (*bin)[kBinWords], int* lp_out, int* lc_out, int* rp_out,
-                                                int* rc_out, uint32_t* nl_out)
+// wave-aggregated counter bump: lanes with `want` get consecutive values, one atomic per wave
+__device__ __forceinline__ uint32_t wave_alloc(uint32_t* counter, bool want, uint32_t lane)
 {
-    int lp[7][6], lc[7][6];
-    uint32_t ln[7];
-#pragma unroll
-    for (int k = 0; k < 6; k++) { lp[0][k] = bin[0][k]; lc[0][k] = bin[0][6 + k]; }
-    ln[0] = (uint32_t)bin[0][12];
-#pragma unroll
-    for (int i = 1; i < 7; i++) {
-#pragma unroll
-        for (int k = 0; k < 6; k++) { lp[i][k] = lp[i - 1][k]; lc[i][k] = lc[i - 1][k]; }
-        ibox_merge(lp[i], &bin[i][0]);
-        ibox_merge(lc[i], &bin[i][6]);
-        ln[i] = ln[i - 1] + (uint32_t)bin[i][12];
-    }
-    int rp[6], rc[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) { rp[k] = bin[7][k]; rc[k] = bin[7][6 + k]; }
-    uint32_t rn = (uint32_t)bin[7][12];
-    float best = 3.402823466e+38f;
-    int plane = -1;
-#pragma unroll
-    for (int i = 6; i >= 0; i--) {
-        float lf[6], rf[6];
-        ibox_to_float(lp[i], lf);
-        ibox_to_float(rp, rf);
-        const float score = sah_sa(lf) * (float)ln[i] + sah_sa(rf) * (float)rn;
-        if (score < best && ln[i] && rn) {
-            best = score; plane = i;
-            *nl_out = ln[i];
-#pragma unroll
-            for (int k = 0; k < 6; k++) { lp_out[k] = lp[i][k]; lc_out[k] = lc[i][k]; rp_out[k] = rp[k]; rc_out[k] = rc[k]; }
-        }
-        ibox_merge(rp, &bin[i][0]);
-        ibox_merge(rc, &bin[i][6]);
-        rn += (uint32_t)bin[i][12];
-    }
-    return plane;
+    const uint64_t m = __builtin_amdgcn_ballot_w64(want);
+    if (m == 0) return 0;
+    uint32_t base = 0;
+    const int leader = __ffsll((unsigned long long)m) - 1;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = __shfl(base, leader, 64);
+    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 }
 
-// one wave per task: plane, parent descriptor, children (RunTask after the bins are known, SharedTaskBuilder.cu:521-606)
-__global__ __launch_bounds__(256) void sah_split_kernel(SahArgs a, uint32_t lvl)
+// one THREAD per task: SelectPlane (SharedTaskBuilder.cu:297-350), parent descriptor, children (RunTask after the
+// bins are known, :521-606).  The two parts that scale with the size of a task -- the child boxes of an object-median
+// split (:465-510) and the per-chunk "goes left" prefix of a task spanning several chunks -- are done by the whole
+// wave, one such task at a time.
+constexpr uint32_t kSplitWaves = 8;
+
+__global__ __launch_bounds__(kSplitWaves * 64) void sah_split_kernel(SahArgs a, uint32_t lvl)
 {
     const uint32_t ntask = a.H->level_count[lvl];
-    const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (w >= ntask) return;
+    if (blockIdx.x * 64 >= ntask) return;
     const uint32_t cur = lvl & 1, nxt = cur ^ 1;
-    const uint32_t lane = threadIdx.x & 63;
-    const SahTask T = a.tasks[cur][w];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ uint32_t pf_c0[64], pf_c1[64], pf_plane[64];
+    __shared__ uint32_t pf_n;
+    if (threadIdx.x == 0) pf_n = 0;
+    __syncthreads();
+    if (wave == 0) {
+    const uint32_t w = blockIdx.x * 64 + lane;
+    const bool valid = w < ntask;
+    SahTask T = {};
+    if (valid) T = a.tasks[cur][w];
     const uint32_t count = T.end - T.start;
     const int bias = (T.flags & 1u) ? -2 * (int)a.n : (int)(2 * kSahCells);
 
     int cb[2][12];   // child boxes, ordered ints: [side][p box 6, c box 6]
+#pragma unroll
+    for (int s = 0; s < 2; s++)
+#pragma unroll
+        for (int k = 0; k < 12; k++) cb[s][k] = (k % 6) < 3 ? kEmptyLo : kEmptyHi;
     uint32_t mid = 0, kind = 2, plane = 0;
-    if (!(sah_sa(T.c) <= 0.0f)) {
-        int bin[8][kBinWords];
+    if (valid && !(sah_sa(T.c) <= 0.0f)) {
         const int* g = a.bins[cur] + (size_t)w * 8 * kBinWords;
+        // prefix left -> right: surface area and count of bins [0, i]
+        float sa_l[7];
+        uint32_t ln[7];
+        {
+            int run[6] = {kEmptyLo, kEmptyLo, kEmptyLo, kEmptyHi, kEmptyHi, kEmptyHi};
+            uint32_t c = 0;
 #pragma unroll
-        for (int b = 0; b < 8; b++)
+            for (int i = 0; i < 7; i++) {
+                ibox_merge(run, g + i * kBinWords);
+                c += (uint32_t)g[i * kBinWords + 12];
+                float f[6];
+                ibox_to_float(run, f);
+                sa_l[i] = sah_sa(f);
+                ln[i] = c;
+            }
+        }
+        // sweep right -> left, strict <, both sides non-empty: the highest plane wins ties
+        int run[6];
 #pragma unroll
-            for (int k = 0; k < (int)kBinWords; k++) bin[b][k] = g[b * kBinWords + k];
-        uint32_t nl = 0;
-        const int pl = sah_select_plane(bin, &cb[0][0], &cb[0][6], &cb[1][0], &cb[1][6], &nl);
-        if (pl >= 0) { kind = 1; plane = (uint32_t)pl; mid = T.start + nl; }
+        for (int k = 0; k < 6; k++) run[k] = g[7 * kBinWords + k];
+        uint32_t rn = (uint32_t)g[7 * kBinWords + 12];
+        float best = 3.402823466e+38f;
+        int pl = -1;
+#pragma unroll
+        for (int i = 6; i >= 0; i--) {
+            float f[6];
+            ibox_to_float(run, f);
+            const float score = sa_l[i] * (float)ln[i] + sah_sa(f) * (float)rn;
+            if (score < best && ln[i] && rn) { best = score; pl = i; }
+            ibox_merge(run, g + i * kBinWords);
+            rn += (uint32_t)g[i * kBinWords + 12];
+        }
+        if (pl >= 0) {
+            kind = 1; plane = (uint32_t)pl; mid = T.start + ln[pl];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if (i <= pl) { ibox_merge(&cb[0][0], g + i * kBinWords); ibox_merge(&cb[0][6], g + i * kBinWords + 6); }
+                else { ibox_merge(&cb[1][0], g + i * kBinWords); ibox_merge(&cb[1][6], g + i * kBinWords + 6); }
+            }
+        }
     }
-    if (kind == 2) {
-        // object split at the midpoint (SharedTaskBuilder.cu:465-510): child boxes by a wave reduction over the items
-        mid = T.start + (count >> 1);
+    if (valid && kind == 2) mid = T.start + (count >> 1);
+    // object split at the midpoint: child boxes by a wave reduction over the items, one task at a time
+    for (uint64_t todo = __builtin_amdgcn_ballot_w64(valid && kind == 2); todo; todo &= todo - 1) {
+        const int src = __ffsll((unsigned long long)todo) - 1;
+        const uint32_t ts = __shfl(T.start, src, 64), te = __shfl(T.end, src, 64), tm = __shfl(mid, src, 64);
         int v[2][12];
 #pragma unroll
         for (int s = 0; s < 2; s++)
 #pragma unroll
             for (int k = 0; k < 12; k++) v[s][k] = (k % 6) < 3 ? kEmptyLo : kEmptyHi;
-        for (uint32_t i = T.start + lane; i < T.end; i += 64) {
+        for (uint32_t i = ts + lane; i < te; i += 64) {
             float b[6];
             load_box(a.aabbs, a.ids[cur][i] & kIdMask, b);
-            const int s = i >= mid;
+            const bool right = i >= tm;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const int ctr = float_to_ordered_int((b[3 + k] + b[k]) * 0.5f);
                 const int lo = float_to_ordered_int(b[k]), hi = float_to_ordered_int(b[3 + k]);
-                if (s) { v[1][k] = min(v[1][k], lo); v[1][3 + k] = max(v[1][3 + k], hi); v[1][6 + k] = min(v[1][6 + k], ctr); v[1][9 + k] = max(v[1][9 + k], ctr); }
+                if (right) { v[1][k] = min(v[1][k], lo); v[1][3 + k] = max(v[1][3 + k], hi); v[1][6 + k] = min(v[1][6 + k], ctr); v[1][9 + k] = max(v[1][9 + k], ctr); }
                 else { v[0][k] = min(v[0][k], lo); v[0][3 + k] = max(v[0][3 + k], hi); v[0][6 + k] = min(v[0][6 + k], ctr); v[0][9 + k] = max(v[0][9 + k], ctr); }
             }
         }
 #pragma unroll
         for (int s = 0; s < 2; s++)
 #pragma unroll
-            for (int k = 0; k < 12; k++) cb[s][k] = (k % 6) < 3 ? wave_min_i32(v[s][k]) : wave_max_i32(v[s][k]);
+            for (int k = 0; k < 12; k++) {
+                const int r = (k % 6) < 3 ? wave_min_i32(v[s][k]) : wave_max_i32(v[s][k]);
+                if ((int)lane == src) cb[s][k] = r;
+            }
     }
     const uint32_t child_index = (uint32_t)(bias + 2 * (int)mid);
-    const uint32_t cs[2] = {T.start, mid}, ce[2] = {mid, T.end};
-    uint32_t cid[2];
+    uint32_t cid[2] = {kInactive, kInactive};
 #pragma unroll
     for (int s = 0; s < 2; s++) {
-        const uint32_t cc = ce[s] - cs[s];
-        uint32_t id = kInactive;
-        if (cc > kSahSmall) {
-            if (lane == 0) id = atomicAdd(&a.H->level_count[lvl + 1], 1u);
-            id = __builtin_amdgcn_readfirstlane(id);
-            if (lane == 0) {
-                SahTask C;
-                for (int k = 0; k < 6; k++) { C.p[k] = ordered_int_to_float(cb[s][k]); C.c[k] = ordered_int_to_float(cb[s][6 + k]); }
-                C.start = cs[s]; C.end = ce[s]; C.parent_idx = child_index + s; C.flags = T.flags;
-                a.tasks[nxt][id] = C;
-            }
-            sah_init_bins(a.bins[nxt], id, lane, 64);
-        } else if (lane == 0) {
-            const uint32_t sidx = atomicAdd(&a.H->small_count, 1u);
-            a.small[sidx] = SahSmall{cs[s], ce[s], child_index + s, (T.flags & 1u) | (nxt << 1)};
+        const uint32_t cs = s ? mid : T.start, ce = s ? T.end : mid;
+        const bool big = valid && (ce - cs) > kSahSmall;
+        const uint32_t id = wave_alloc(&a.H->level_count[lvl + 1], big, lane);
+        const uint32_t sidx = wave_alloc(&a.H->small_count, valid && !big, lane);
+        if (big) {
+            SahTask C;
+#pragma unroll
+            for (int k = 0; k < 6; k++) { C.p[k] = ordered_int_to_float(cb[s][k]); C.c[k] = ordered_int_to_float(cb[s][6 + k]); }
+            C.start = cs; C.end = ce; C.parent_idx = child_index + s; C.flags = T.flags;
+            a.tasks[nxt][id] = C;
+            sah_init_bins(a.bins[nxt], id, 0, 1);
+            cid[s] = id;
+        } else if (valid) {
+            a.small[sidx] = SahSmall{cs, ce, child_index + (uint32_t)s, (T.flags & 1u) | (nxt << 1)};
         }
-        cid[s] = id;
     }
-    if (lane == 0) {
+    if (valid) {
         sah_put_node(a.nodes + T.parent_idx, T.p, child_index, 2u, RT_CHILD_BOX);
         SahSplit S;
         S.kind = kind; S.plane = plane; S.mid = mid; S.left_id = cid[0]; S.right_id = cid[1];
         S.pad[0] = S.pad[1] = S.pad[2] = 0;
         a.splits[w] = S;
     }
-    // "goes left" prefix per chunk for a task that spans several chunks (stable partition across workgroups)
-    const uint32_t c0 = T.start / kSahChunk, c1 = (T.end - 1) / kSahChunk;
-    if (kind == 1 && c1 > c0) {
+    // tasks that span several chunks need the per-chunk "goes left" prefix: queued for the whole workgroup
+    const uint32_t c0 = T.start / kSahChunk, c1 = valid ? (T.end - 1) / kSahChunk : 0;
+    if (valid && kind == 1 && c1 > c0) {
+        const uint32_t q = atomicAdd(&pf_n, 1u);
+        pf_c0[q] = c0; pf_c1[q] = c1; pf_plane[q] = plane;
+    }
+    }   // wave 0
+    __syncthreads();
+    // "goes left" prefix per chunk (stable partition across workgroups): one wave per queued task
+    for (uint32_t q = wave; q < pf_n; q += kSplitWaves) {
+        const uint32_t k0 = pf_c0[q], k1 = pf_c1[q], pl = pf_plane[q];
         uint32_t running = 0;
-        for (uint32_t base = c0; base <= c1; base += 64) {
+        for (uint32_t base = k0; base <= k1; base += 64) {
             const uint32_t c = base + lane;
             uint32_t v = 0;
-            if (c <= c1) {
-                const uint32_t* h = a.chunk_hist + (size_t)c * 16 + (c == c0 ? 8 : 0);
-                for (uint32_t b = 0; b <= plane; b++) v += h[b];
+            if (c <= k1) {
+                const uint32_t* h = a.chunk_hist + (size_t)c * 16 + (c == k0 ? 8 : 0);
+                for (uint32_t b = 0; b <= pl; b++) v += h[b];
             }
             const uint32_t incl = wave_incl_scan_u32(v, (int)lane);
-            if (c <= c1 && c > c0) a.chunk_prefix[c] = running + incl - v;
+            if (c <= k1 && c > k0) a.chunk_prefix[c] = running + incl - v;
             running += __shfl(incl, 63, 64);
         }
     }
@@ -614,142 +695,181 @@ __global__ __launch_bounds__(256) void sah_partition_kernel(SahArgs a, uint32_t 
 }
 
 // ---------------------------------------------------------------------------------------------
-// one thread per small task: the whole sub-tree, depth first (PerInstanceRunTask, SharedTaskBuilder.cu:742-907)
+// one WAVE per small task (<= 64 items): the whole sub-tree, level by level, every sub-task of a level at once.
+// (The reference finishes small tasks with one thread each, PerInstanceRunTask, SharedTaskBuilder.cu:742-907.)
+// Lane l holds the item at position start + l (id and box in registers); a sub-task is a lane range [s, e).  Per level:
+// bins of every sub-task in LDS (integer atomics), plane selection by the sub-task's first lane, child boxes by LDS
+// atomics, stable partition with ballots, items moved to their new lanes with ds_permute.
+constexpr uint32_t kSmallSegs = 22;   // sub-tasks with >= 3 items alive in one level (<= 64 / 3)
+
+struct SmallSmem {
+    int sbox[2][64][12];              // [buffer][first lane of the sub-task][p box 6, c box 6], ordered ints
+    int bins[kSmallSegs][8][6];       // primitive box per bin
+    uint32_t splane[64], snl[64], skind[64];
+};
+
 __global__ __launch_bounds__(64) void sah_small_kernel(SahArgs a)
 {
-    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= a.H->small_count) return;
-    const SahSmall R = a.small[i];
+    __shared__ SmallSmem S;
+    const SahSmall R = a.small[blockIdx.x];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t cnt = R.end - R.start, base = R.start;
     const int bias = (R.flags & 1u) ? -2 * (int)a.n : (int)(2 * kSahCells);
-    const uint32_t base = R.start;
-    uint32_t idbuf[2][kSahSmall];
-    {
-        const uint32_t* src = a.ids[(R.flags >> 1) & 1u];
-        for (uint32_t k = 0; k < R.end - R.start; k++) idbuf[0][k] = src[R.start + k];
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+
+    uint32_t idv = 0;
+    float b[6] = {0, 0, 0, 0, 0, 0};
+    if (lane < cnt) {
+        idv = a.ids[(R.flags >> 1) & 1u][base + lane];
+        load_box(a.aabbs, idv & kIdMask, b);
     }
-    uint32_t s_start[kSahSmall], s_end[kSahSmall], s_parent[kSahSmall], s_buf[kSahSmall];
-    uint32_t sp = 0;
-    s_start[0] = R.start; s_end[0] = R.end; s_parent[0] = R.parent_idx; s_buf[0] = 0;
-    sp = 1;
-    bool use_gc = (R.flags & 4u) != 0;   // the top root's centroid bounds are the scene's (BuildWrapper.cu:245-249)
-    while (sp) {
-        --sp;
-        const uint32_t ts = s_start[sp], te = s_end[sp], parent = s_parent[sp], buf = s_buf[sp];
-        const uint32_t count = te - ts;
-        const uint32_t* in = idbuf[buf];
-        uint32_t* out = idbuf[buf ^ 1];
-        int pi[6], ci[6];
+    uint32_t s = 0, e = cnt, parent = R.parent_idx;
+    bool active = lane < cnt;
+    uint32_t cur = 0;
+    // root boxes
+    for (uint32_t j = lane; j < 64 * 12; j += 64) (&S.sbox[0][0][0])[j] = (j % 6) < 3 ? kEmptyLo : kEmptyHi;
+    __syncthreads();
+    if (active) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) { pi[k] = k < 3 ? kEmptyLo : kEmptyHi; ci[k] = pi[k]; }
-        for (uint32_t p = ts; p < te; p++) {
-            float b[6];
-            load_box(a.aabbs, in[p - base] & kIdMask, b);
+        for (int k = 0; k < 3; k++) {
+            const int ctr = float_to_ordered_int((b[k] + b[3 + k]) * 0.5f);
+            atomicMin(&S.sbox[0][0][k], float_to_ordered_int(b[k]));
+            atomicMax(&S.sbox[0][0][3 + k], float_to_ordered_int(b[3 + k]));
+            atomicMin(&S.sbox[0][0][6 + k], ctr);
+            atomicMax(&S.sbox[0][0][9 + k], ctr);
+        }
+    }
+    __syncthreads();
+    if ((R.flags & 4u) && lane < 6) S.sbox[0][0][6 + lane] = a.H->gc[lane];   // the top root's centroid bounds are the scene's
+    __syncthreads();
+
+    while (__builtin_amdgcn_ballot_w64(active)) {
+        const uint32_t nxt = cur ^ 1;
+        const uint32_t count = e - s;
+        // ---- leaves (SharedTaskBuilder.cu:396-464)
+        if (active && count <= 2) {
+            if (count == 1) {
+                sah_leaf_desc(a, a.nodes + parent, idv);
+            } else {
+                const uint32_t child = (uint32_t)(bias + 2 * (int)(base + s + 1));
+                sah_leaf_desc(a, a.nodes + child + (lane - s), idv);
+                if (lane == s) {
+                    float pb[6];
+                    ibox_to_float(&S.sbox[cur][s][0], pb);
+                    sah_put_node(a.nodes + parent, pb, child, 2u, RT_CHILD_BOX);
+                }
+            }
+            active = false;
+        }
+        // ---- bin
+        const bool leader = active && lane == s;
+        const uint64_t leaders = __builtin_amdgcn_ballot_w64(leader);
+        const uint32_t nseg = (uint32_t)__popcll(leaders);
+        const uint32_t seg = (uint32_t)__popcll(leaders & ((1ull << s) - 1ull));
+        const uint64_t segmask = active ? (((e >= 64 ? ~0ull : ((1ull << e) - 1ull))) & ~((1ull << s) - 1ull)) : 0ull;
+        for (uint32_t j = lane; j < nseg * 48; j += 64) (&S.bins[0][0][0])[j] = (j % 6) < 3 ? kEmptyLo : kEmptyHi;
+        for (uint32_t j = lane; j < 64 * 12; j += 64) (&S.sbox[nxt][0][0])[j] = (j % 6) < 3 ? kEmptyLo : kEmptyHi;
+        float c[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) c[k] = active ? ordered_int_to_float(S.sbox[cur][s][6 + k]) : 0.0f;
+        const bool binned = active && !(sah_sa(c) <= 0.0f);
+        int bin = 0;
+        if (binned) {
+            const int axis = sah_axis(c);
+            const float epsilon = 1.1920929e-7f;
+            const float cmin = axis == 0 ? c[0] : (axis == 1 ? c[1] : c[2]);
+            const float cmax = axis == 0 ? c[3] : (axis == 1 ? c[4] : c[5]);
+            const float k1 = 8 * (1 - epsilon) / (cmax - cmin);
+            const float ca = axis == 0 ? (b[0] + b[3]) * 0.5f : (axis == 1 ? (b[1] + b[4]) * 0.5f : (b[2] + b[5]) * 0.5f);
+            bin = min(7, max(0, cvt_rzi(k1 * (ca - cmin))));
+        }
+        __syncthreads();
+        if (binned) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                atomicMin(&S.bins[seg][bin][k], float_to_ordered_int(b[k]));
+                atomicMax(&S.bins[seg][bin][3 + k], float_to_ordered_int(b[3 + k]));
+            }
+        }
+        uint32_t bn[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) bn[q] = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(binned && bin == q) & segmask);
+        __syncthreads();
+        // ---- SelectPlane (SharedTaskBuilder.cu:297-350) by the first lane of each sub-task
+        if (leader) {
+            uint32_t kind = 2, plane = 0, nl = count >> 1;
+            if (binned) {
+                float sa_l[7];
+                uint32_t ln[7];
+                int run[6] = {kEmptyLo, kEmptyLo, kEmptyLo, kEmptyHi, kEmptyHi, kEmptyHi};
+                uint32_t cc = 0;
+#pragma unroll
+                for (int i = 0; i < 7; i++) {
+                    ibox_merge(run, &S.bins[seg][i][0]);
+                    cc += bn[i];
+                    float f[6];
+                    ibox_to_float(run, f);
+                    sa_l[i] = sah_sa(f);
+                    ln[i] = cc;
+                }
+#pragma unroll
+                for (int k = 0; k < 6; k++) run[k] = S.bins[seg][7][k];
+                uint32_t rn = bn[7];
+                float best = 3.402823466e+38f;
+                int pl = -1;
+#pragma unroll
+                for (int i = 6; i >= 0; i--) {
+                    float f[6];
+                    ibox_to_float(run, f);
+                    const float score = sa_l[i] * (float)ln[i] + sah_sa(f) * (float)rn;
+                    if (score < best && ln[i] && rn) { best = score; pl = i; nl = ln[i]; }
+                    ibox_merge(run, &S.bins[seg][i][0]);
+                    rn += bn[i];
+                }
+                if (pl >= 0) { kind = 1; plane = (uint32_t)pl; } else nl = count >> 1;
+            }
+            S.skind[s] = kind; S.splane[s] = plane; S.snl[s] = nl;
+            // parent descriptor (SharedTaskBuilder.cu:544-558)
+            float pb[6];
+            ibox_to_float(&S.sbox[cur][s][0], pb);
+            sah_put_node(a.nodes + parent, pb, (uint32_t)(bias + 2 * (int)(base + s + nl)), 2u, RT_CHILD_BOX);
+        }
+        __syncthreads();
+        // ---- PartitionIds (:352-380), stable; child boxes; move the items
+        uint32_t dest = lane;
+        if (active) {
+            const uint32_t kind = S.skind[s], plane = S.splane[s], nl = S.snl[s];
+            bool left;
+            if (kind == 1) {
+                left = (uint32_t)bin <= plane;
+                const uint64_t lm = __builtin_amdgcn_ballot_w64(left) & segmask;   // (all lanes of the segment are here)
+                const uint32_t lr = (uint32_t)__popcll(lm & lt_mask);
+                dest = left ? s + lr : s + nl + ((lane - s) - lr);
+            } else {
+                left = lane < s + nl;
+            }
+            const uint32_t cs = left ? s : s + nl;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const int ctr = float_to_ordered_int((b[k] + b[3 + k]) * 0.5f);
-                pi[k] = min(pi[k], float_to_ordered_int(b[k])); pi[3 + k] = max(pi[3 + k], float_to_ordered_int(b[3 + k]));
-                ci[k] = min(ci[k], ctr); ci[3 + k] = max(ci[3 + k], ctr);
+                atomicMin(&S.sbox[nxt][cs][k], float_to_ordered_int(b[k]));
+                atomicMax(&S.sbox[nxt][cs][3 + k], float_to_ordered_int(b[3 + k]));
+                atomicMin(&S.sbox[nxt][cs][6 + k], ctr);
+                atomicMax(&S.sbox[nxt][cs][9 + k], ctr);
             }
         }
-        float pbox[6], cbox[6];
-        ibox_to_float(pi, pbox);
-        if (use_gc) { for (int k = 0; k < 6; k++) cbox[k] = ordered_int_to_float(a.H->gc[k]); }
-        else ibox_to_float(ci, cbox);
-        use_gc = false;
-        if (count <= 2) {
-            if (count == 1) { sah_leaf_desc(a, a.nodes + parent, in[ts - base]); continue; }
-            const uint32_t child = (uint32_t)(bias + 2 * (int)(ts + 1));
-            sah_leaf_desc(a, a.nodes + child, in[ts - base]);
-            sah_leaf_desc(a, a.nodes + child + 1, in[ts + 1 - base]);
-            sah_put_node(a.nodes + parent, pbox, child, 2u, RT_CHILD_BOX);
-            continue;
+        // push every item to its new lane (a permutation inside each sub-task; inactive lanes keep theirs)
+        idv = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest * 4), (int)idv);
+#pragma unroll
+        for (int k = 0; k < 6; k++) b[k] = __int_as_float(__builtin_amdgcn_ds_permute((int)(dest * 4), __float_as_int(b[k])));
+        if (active) {
+            const uint32_t nl = S.snl[s];
+            const uint32_t child_index = (uint32_t)(bias + 2 * (int)(base + s + nl));
+            if (lane < s + nl) { e = s + nl; parent = child_index; }
+            else { s = s + nl; parent = child_index + 1; }
         }
-        uint32_t mid = 0;
-        bool done = false;
-        if (!(sah_sa(cbox) <= 0.0f)) {
-            const int axis = sah_axis(cbox);
-            const float epsilon = 1.1920929e-7f;
-            const float cmin = axis == 0 ? cbox[0] : (axis == 1 ? cbox[1] : cbox[2]);
-            const float cmax = axis == 0 ? cbox[3] : (axis == 1 ? cbox[4] : cbox[5]);
-            const float k1 = 8 * (1 - epsilon) / (cmax - cmin);
-            int bp[8][6];
-            uint32_t bn[8];
-#pragma unroll
-            for (int b = 0; b < 8; b++) {
-                bn[b] = 0;
-#pragma unroll
-                for (int k = 0; k < 6; k++) bp[b][k] = k < 3 ? kEmptyLo : kEmptyHi;
-            }
-            uint64_t binmask[2] = {0, 0};   // 3 bits per item, 32 items
-            for (uint32_t p = ts; p < te; p++) {
-                float b[6];
-                load_box(a.aabbs, in[p - base] & kIdMask, b);
-                const float ca = axis == 0 ? (b[0] + b[3]) * 0.5f : (axis == 1 ? (b[1] + b[4]) * 0.5f : (b[2] + b[5]) * 0.5f);
-                const int bin = min(7, max(0, cvt_rzi(k1 * (ca - cmin))));
-                const uint32_t q = p - ts;
-                binmask[q >> 4] |= (uint64_t)bin << ((q & 15) * 4);
-#pragma unroll
-                for (int bb = 0; bb < 8; bb++) {
-                    if (bb == bin) {
-#pragma unroll
-                        for (int k = 0; k < 3; k++) {
-                            bp[bb][k] = min(bp[bb][k], float_to_ordered_int(b[k]));
-                            bp[bb][3 + k] = max(bp[bb][3 + k], float_to_ordered_int(b[3 + k]));
-                        }
-                        bn[bb]++;
-                    }
-                }
-            }
-            // SelectPlane on the primitive boxes only (the children recompute their centroid bounds on entry)
-            int lp[7][6];
-            uint32_t ln[7];
-#pragma unroll
-            for (int k = 0; k < 6; k++) lp[0][k] = bp[0][k];
-            ln[0] = bn[0];
-#pragma unroll
-            for (int j = 1; j < 7; j++) {
-#pragma unroll
-                for (int k = 0; k < 6; k++) lp[j][k] = lp[j - 1][k];
-                ibox_merge(lp[j], bp[j]);
-                ln[j] = ln[j - 1] + bn[j];
-            }
-            int rp[6];
-#pragma unroll
-            for (int k = 0; k < 6; k++) rp[k] = bp[7][k];
-            uint32_t rn = bn[7];
-            float best = 3.402823466e+38f;
-            int plane = -1;
-            uint32_t nl = 0;
-#pragma unroll
-            for (int j = 6; j >= 0; j--) {
-                float lf[6], rf[6];
-                ibox_to_float(lp[j], lf);
-                ibox_to_float(rp, rf);
-                const float score = sah_sa(lf) * (float)ln[j] + sah_sa(rf) * (float)rn;
-                if (score < best && ln[j] && rn) { best = score; plane = j; nl = ln[j]; }
-                ibox_merge(rp, bp[j]);
-                rn += bn[j];
-            }
-            if (plane >= 0) {
-                uint32_t wl = ts, wr = ts + nl;
-                for (uint32_t p = ts; p < te; p++) {
-                    const uint32_t q = p - ts;
-                    const int bin = (int)((binmask[q >> 4] >> ((q & 15) * 4)) & 15u);
-                    if (bin <= plane) out[wl++ - base] = in[p - base];
-                    else out[wr++ - base] = in[p - base];
-                }
-                mid = ts + nl;
-                done = true;
-            }
-        }
-        if (!done) {
-            mid = ts + (count >> 1);
-            for (uint32_t p = ts; p < te; p++) out[p - base] = in[p - base];
-        }
-        const uint32_t child_index = (uint32_t)(bias + 2 * (int)mid);
-        sah_put_node(a.nodes + parent, pbox, child_index, 2u, RT_CHILD_BOX);
-        s_start[sp] = mid; s_end[sp] = te; s_parent[sp] = child_index + 1; s_buf[sp] = buf ^ 1; sp++;
-        s_start[sp] = ts; s_end[sp] = mid; s_parent[sp] = child_index; s_buf[sp] = buf ^ 1; sp++;
+        cur = nxt;
+        __syncthreads();
     }
 }
 
@@ -840,8 +960,8 @@ hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, rt_
         hipError_t e = launch_pair_slots(tris, n, pflags, psums, num_leaves, st);
         if (e != hipSuccess) return e;
     }
-    sah_setup_kernel<<<cblocks, 256, 0, st>>>(reinterpret_cast<const float*>(tris), n, leaves, aabbs, a.ids[1], a.H, pflags, psums);
-    sah_grid_kernel<<<(n + 255) / 256, 256, 0, st>>>(aabbs, n, n_dev, a.H, a.task_of[1]);
+    sah_setup_kernel<<<cblocks < 256 ? cblocks : 256, 256, 0, st>>>(reinterpret_cast<const float*>(tris), n, leaves, aabbs, a.ids[1], a.H, pflags, psums);
+    sah_grid_kernel<<<(n + 255) / 256 < 256 ? (n + 255) / 256 : 256, 256, 0, st>>>(aabbs, n, n_dev, a.H, a.task_of[1]);
     // GridBlockDistribute: cell members in ascending leaf index = one stable radix pass on the cell id
     uint32_t* digit_total = nullptr;
     hipError_t e = launch_radix_pass(a.task_of[1], a.ids[1], a.task_of[0], a.ids[0], n, 0, s + L.sort, st, n_dev, &digit_total);
@@ -851,17 +971,22 @@ hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, rt_
 
     const uint32_t chunks = (a.M + kSahChunk - 1) / kSahChunk;
     const uint32_t TA = a.M / (kSahSmall + 1) + 2;
-    const uint32_t split_blocks = (TA + 3) / 4;
+    const uint32_t split_blocks = (TA + 63) / 64;
     uint32_t lvl = 0;
-    uint32_t batch = 16;
+    // levels until every task has <= kSahSmall items: about log2(items per cell / kSahSmall) when the splits are
+    // balanced; the first batch adds a margin, later batches are short
+    uint32_t batch = 3;
+    for (uint32_t per_cell = n / kSahCells; per_cell > kSahSmall; per_cell >>= 1) batch++;
+    uint32_t nsmall = 0;
     while (true) {
         for (uint32_t i = 0; i < batch && lvl + 1 < kSahMaxLevels; i++, lvl++) {
             sah_bin_kernel<<<chunks, 256, 0, st>>>(a, lvl);
-            sah_split_kernel<<<split_blocks, 256, 0, st>>>(a, lvl);
+            sah_split_kernel<<<split_blocks, kSplitWaves * 64, 0, st>>>(a, lvl);
             sah_partition_kernel<<<chunks, 256, 0, st>>>(a, lvl);
         }
         uint32_t live = 0;
         e = hipMemcpyAsync(&live, &a.H->level_count[lvl], 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(&nsmall, &a.H->small_count, 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) return e;
         if (live == 0) break;
@@ -871,14 +996,10 @@ hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, rt_
             (void)hipStreamSynchronize(st);
             break;
         }
-        batch = 8;
+        batch = 4;
     }
     if (levels_run) *levels_run = lvl;
-    uint32_t nsmall = 0;
-    e = hipMemcpyAsync(&nsmall, &a.H->small_count, 4, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) return e;
-    if (nsmall) sah_small_kernel<<<(nsmall + 63) / 64, 64, 0, st>>>(a);
+    if (nsmall) sah_small_kernel<<<nsmall, 64, 0, st>>>(a);
     sah_patch_top_kernel<<<1, 128, 0, st>>>(a);
     return hipGetLastError();
 }
