@@ -708,11 +708,25 @@ struct SmallSmem {
     uint32_t splane[64], snl[64], skind[64];
 };
 
-__global__ __launch_bounds__(64) void sah_small_kernel(SahArgs a)
+// LDS traffic between the lanes of ONE wave: its DS operations execute in order, so only the compiler has to be kept
+// from moving memory operations across the point
+__device__ __forceinline__ void wave_lds_sync()
 {
-    __shared__ SmallSmem S;
-    const SahSmall R = a.small[blockIdx.x];
-    const uint32_t lane = threadIdx.x;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr uint32_t kSmallWaves = 4;   // independent waves per workgroup (single-wave workgroups are dispatch bound)
+
+__global__ __launch_bounds__(kSmallWaves * 64) void sah_small_kernel(SahArgs a, uint32_t nsmall)
+{
+    __shared__ SmallSmem SS[kSmallWaves];
+    const uint32_t task = blockIdx.x * kSmallWaves + (threadIdx.x >> 6);
+    if (task >= nsmall) return;
+    SmallSmem& S = SS[threadIdx.x >> 6];
+    const SahSmall R = a.small[task];
+    const uint32_t lane = threadIdx.x & 63;
     const uint32_t cnt = R.end - R.start, base = R.start;
     const int bias = (R.flags & 1u) ? -2 * (int)a.n : (int)(2 * kSahCells);
     const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -728,7 +742,7 @@ __global__ __launch_bounds__(64) void sah_small_kernel(SahArgs a)
     uint32_t cur = 0;
     // root boxes
     for (uint32_t j = lane; j < 64 * 12; j += 64) (&S.sbox[0][0][0])[j] = (j % 6) < 3 ? kEmptyLo : kEmptyHi;
-    __syncthreads();
+    wave_lds_sync();
     if (active) {
 #pragma unroll
         for (int k = 0; k < 3; k++) {
@@ -739,9 +753,9 @@ __global__ __launch_bounds__(64) void sah_small_kernel(SahArgs a)
             atomicMax(&S.sbox[0][0][9 + k], ctr);
         }
     }
-    __syncthreads();
+    wave_lds_sync();
     if ((R.flags & 4u) && lane < 6) S.sbox[0][0][6 + lane] = a.H->gc[lane];   // the top root's centroid bounds are the scene's
-    __syncthreads();
+    wave_lds_sync();
 
     while (__builtin_amdgcn_ballot_w64(active)) {
         const uint32_t nxt = cur ^ 1;
@@ -783,7 +797,7 @@ __global__ __launch_bounds__(64) void sah_small_kernel(SahArgs a)
             const float ca = axis == 0 ? (b[0] + b[3]) * 0.5f : (axis == 1 ? (b[1] + b[4]) * 0.5f : (b[2] + b[5]) * 0.5f);
             bin = min(7, max(0, cvt_rzi(k1 * (ca - cmin))));
         }
-        __syncthreads();
+        wave_lds_sync();
         if (binned) {
 #pragma unroll
             for (int k = 0; k < 3; k++) {
@@ -794,7 +808,7 @@ __global__ __launch_bounds__(64) void sah_small_kernel(SahArgs a)
         uint32_t bn[8];
 #pragma unroll
         for (int q = 0; q < 8; q++) bn[q] = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(binned && bin == q) & segmask);
-        __syncthreads();
+        wave_lds_sync();
         // ---- SelectPlane (SharedTaskBuilder.cu:297-350) by the first lane of each sub-task
         if (leader) {
             uint32_t kind = 2, plane = 0, nl = count >> 1;
@@ -834,7 +848,7 @@ __global__ __launch_bounds__(64) void sah_small_kernel(SahArgs a)
             ibox_to_float(&S.sbox[cur][s][0], pb);
             sah_put_node(a.nodes + parent, pb, (uint32_t)(bias + 2 * (int)(base + s + nl)), 2u, RT_CHILD_BOX);
         }
-        __syncthreads();
+        wave_lds_sync();
         // ---- PartitionIds (:352-380), stable; child boxes; move the items
         uint32_t dest = lane;
         if (active) {
@@ -869,7 +883,7 @@ __global__ __launch_bounds__(64) void sah_small_kernel(SahArgs a)
             else { s = s + nl; parent = child_index + 1; }
         }
         cur = nxt;
-        __syncthreads();
+        wave_lds_sync();
     }
 }
 
@@ -999,7 +1013,7 @@ hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, rt_
         batch = 4;
     }
     if (levels_run) *levels_run = lvl;
-    if (nsmall) sah_small_kernel<<<nsmall, 64, 0, st>>>(a);
+    if (nsmall) sah_small_kernel<<<(nsmall + kSmallWaves - 1) / kSmallWaves, kSmallWaves * 64, 0, st>>>(a, nsmall);
     sah_patch_top_kernel<<<1, 128, 0, st>>>(a);
     return hipGetLastError();
 }
