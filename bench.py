@@ -235,7 +235,7 @@ def main():
     if rank == 0:
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "trace_traffic.json")
-        if os.path.exists(tpath) and world == 1 and cam == "a" and (W, H, G, args.spp) == (1920, 1080, 708, 1):
+        if os.path.exists(tpath) and world == 1 and cam == "a" and (W, H, G, args.spp) == (1920, 1080, 708, 1) and not sah:
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
