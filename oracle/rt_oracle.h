@@ -16,7 +16,13 @@
  * arithmetic of Morton codes / sort / traversal is "parity unpinned" against reference-held
  * vectors.  What IS pinned: (1) the reference's own structural check -- VerifyHierarchy and
  * CountNodes from Utilities.cpp compiled unmodified into oracle/_ref -- is run on the oracle's
- * (and the GPU's) Node arrays; (2) the node-count identities of SURVEY.md Appendix A.
+ * (and the GPU's) Node arrays, for the bottom-up, hybrid, pairs and SAH trees alike; (2) the
+ * node-count identities of SURVEY.md Appendix A; (3) trees of the same triangles are checked
+ * against each other (the SAH and hybrid trees render the same kDepth frame as the LBVH).
+ * The hybrid, pairs and SAH builders of the reference number nodes / leaves by atomic arrival
+ * order, so for those the restatement fixes one deterministic numbering (stated at each function)
+ * and parity with the reference is structural.  The textured render types have no reference
+ * frame either: pinned by properties (tests/test_oracle_textures.py).
  */
 #ifndef RT_ORACLE_H
 #define RT_ORACLE_H

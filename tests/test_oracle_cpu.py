@@ -249,3 +249,40 @@ def test_pairs_oracle(ora, scenes):
             i1, _ = ora.trace(b["leaves"], b["nodes"], 0, 2, cam, 96, 64, render_type=rtype, attributes=at, materials=mats, light=tuple(hi + 1))
             i2, _ = ora.trace(p["leaves"], p["nodes"], 0, 2, cam, 96, 64, render_type=rtype, attributes=at, materials=mats, light=tuple(hi + 1))
             assert (i1 == i2).all(), rtype
+
+
+@pytest.mark.parametrize("pairs", [False, True])
+@pytest.mark.parametrize("scene", ["grid30", "soup3000", "flat12", "coincident"])
+def test_sah_oracle_tree_is_valid_and_renders_like_the_lbvh(scene, pairs, scenes, ora):
+    """ora_build_sah (RunSahBuild restated): checked by the reference's compiled VerifyHierarchy / CountNodes, by every
+    leaf being referenced exactly once, by the grid-cell counts adding up, and by tracing: the same triangles give the
+    same nearest hits as through the LBVH (kDepth frames equal), with fewer box tests on the mesh."""
+    tris = {"grid30": scenes.grid_mesh(30, 2), "soup3000": scenes.soup(3000, 5),
+            "flat12": scenes.flat_mesh(12, 3),
+            "coincident": np.repeat(scenes.soup(6, 3, dup_fraction=0.0), 100, axis=0)}[scene]
+    s = ora.build_sah(tris, pairs)
+    L = s["L"]
+    assert int(s["cell_counts"].sum()) == L
+    assert ora.count_nodes(s["nodes"], 0, 1) == (2 * L - 1, L, L - 1)
+    assert ora.verify_hierarchy(s["nodes"], 0, 1) == 0
+    if ora.ref_available():
+        assert ora.ref_count_nodes(s["nodes"], 0, 1) == (2 * L - 1, L, L - 1)
+        assert ora.ref_verify_hierarchy(s["nodes"], 0, 1) == ""
+    w28 = s["nodes"]["w28"]
+    ids = w28[(w28 >> 29) == 2] & 0x1FFFFFFF
+    # every leaf referenced; a cell holding ONE leaf has a Tri sub-root that the top tree copies (so it appears twice,
+    # the sub-root copy being unreachable) -- CountNodes above counted the reachable ones: exactly L
+    assert (np.unique(ids) == np.arange(L)).all()
+    assert ids.shape[0] - L == int((s["cell_counts"] == 1).sum())
+    # the top tree lives in slots [0, 128), cell trees above; a Box slot never points below its own region
+    box = (w28 >> 29) == 1
+    assert ((w28[128:][box[128:]] & 0x1FFFFFFF) >= 128).all()
+    if not pairs:
+        b = ora.build_bvh(tris)
+        lo, hi = tris.reshape(-1, 3).min(axis=0), tris.reshape(-1, 3).max(axis=0)
+        cam = scenes.camera_for_box(lo, hi)
+        f0, c0 = ora.trace(b["leaves"], b["nodes"], 0, 2, cam, 96, 64, render_type=0)
+        f1, c1 = ora.trace(s["leaves"], s["nodes"], 0, 1, cam, 96, 64, render_type=0)
+        assert (f0 == f1).all()
+        if scene == "grid30":
+            assert c1[0] < c0[0]
