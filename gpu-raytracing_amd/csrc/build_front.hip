@@ -243,6 +243,12 @@ hipError_t launch_morton_pairs(uint32_t* codes, uint32_t* values, const rt_trian
     return hipGetLastError();
 }
 
+hipError_t launch_block_scan(uint32_t* sums, uint32_t count, uint32_t* total, hipStream_t st)
+{
+    pair_scan_kernel<<<1, 1024, 0, st>>>(sums, count, total);
+    return hipGetLastError();
+}
+
 hipError_t launch_pair_slots(const rt_triangle* tris, uint32_t n, uint8_t* flags, uint32_t* block_sums,
                              uint32_t* num_leaves, hipStream_t st)
 {

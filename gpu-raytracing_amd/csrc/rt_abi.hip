@@ -100,7 +100,7 @@ int rt_run_bottom_up_build(const rt_build_input* input, const rt_arguments* args
     const uint32_t n = input->num_triangles;
     if (n && (!input->triangles_in || !input->triangles_out)) return RT_ERR_INVALID_ARGUMENT;
     if (n > (1u << 28)) return RT_ERR_TOO_LARGE;  // 2(n-1) slots must fit the 29-bit child field
-    if (args && args->enable_splits) return RT_ERR_UNSUPPORTED;  // SURVEY 8(f) rank 3 (spatial-split pre-pass of the SAH path)
+    // args->enable_splits is ignored here, as in the reference: only RunSahBuild has a split pre-pass (BuildWrapper.cu:188-210)
     const bool pairs = args && args->enable_pairs;
     if ((reinterpret_cast<uintptr_t>(input->scratch) & 255u) || (reinterpret_cast<uintptr_t>(input->triangles_in) & 15u) ||
         (reinterpret_cast<uintptr_t>(input->triangles_out) & 63u) || (reinterpret_cast<uintptr_t>(input->nodes_out) & 63u))
@@ -159,12 +159,12 @@ int rt_run_sah_build(const rt_build_input* input, const rt_arguments* args, void
     if (!input || !input->nodes_out || !input->scratch) return RT_ERR_INVALID_ARGUMENT;
     const uint32_t n = input->num_triangles;
     if (n && (!input->triangles_in || !input->triangles_out)) return RT_ERR_INVALID_ARGUMENT;
-    if (n > (1u << 28) - 64) return RT_ERR_TOO_LARGE;
-    if (args && args->enable_splits) return RT_ERR_UNSUPPORTED;  // SetupSplits / SetupPairSplits (Multiblock.cu:209-425)
+    const bool splits = args && args->enable_splits;
+    if (n > (splits ? (1u << 25) : (1u << 28) - 64)) return RT_ERR_TOO_LARGE;   // splits: the 32-bit budget prefix sums 63 per leaf
     if ((reinterpret_cast<uintptr_t>(input->scratch) & 255u) || (reinterpret_cast<uintptr_t>(input->triangles_in) & 15u) ||
         (reinterpret_cast<uintptr_t>(input->triangles_out) & 63u) || (reinterpret_cast<uintptr_t>(input->nodes_out) & 63u))
         return RT_ERR_INVALID_ARGUMENT;
-    return hip_rc(launch_sah_build(input->triangles_in, n, args && args->enable_pairs, input->triangles_out, input->nodes_out,
+    return hip_rc(launch_sah_build(input->triangles_in, n, args && args->enable_pairs, splits, input->triangles_out, input->nodes_out,
                                    input->scratch, static_cast<hipStream_t>(stream), nullptr));
 }
 

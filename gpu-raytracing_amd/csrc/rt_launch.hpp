@@ -64,7 +64,7 @@ BuLayout bu_layout(uint32_t n);
 // ---- SAH build scratch (sah_build.hip)
 struct SahLayout {
     size_t header, aabbs, ids0, ids1, task_of0, task_of1, binof, tasks0, tasks1, splits, bins0, bins1, chunk_hist,
-        chunk_prefix, small, sort, pair_flags, pair_sums;
+        chunk_prefix, small, sort, pair_flags, pair_sums, item_leaf, split_flags, split_sums_a, split_sums_b;
     size_t status;       // uint32[8] inside the header: [0] error flags, [1] number of leaves L
     size_t cell_counts;  // uint32[64] inside the header
     size_t total;
@@ -94,8 +94,10 @@ hipError_t launch_radix_pass(const uint32_t* keys_in, const uint32_t* vals_in, u
 hipError_t launch_pair_slots(const rt_triangle* tris, uint32_t n, uint8_t* flags, uint32_t* block_sums,
                              uint32_t* num_leaves, hipStream_t st);
 // RunSahBuild (no splits).  Synchronises the stream (data-dependent number of levels).
-hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, rt_triangle_pair* leaves, rt_node* nodes,
-                            void* scratch, hipStream_t st, uint32_t* levels_run);
+hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, bool splits, rt_triangle_pair* leaves,
+                            rt_node* nodes, void* scratch, hipStream_t st, uint32_t* levels_run);
+// in-place exclusive scan of per-workgroup sums (one workgroup); *total = their sum
+hipError_t launch_block_scan(uint32_t* sums, uint32_t count, uint32_t* total, hipStream_t st);
 
 hipError_t launch_hybrid_top(rt_node* nodes, const int* aabb_ordered, uint32_t n, hipStream_t st,
                              const uint32_t* n_dev = nullptr);

@@ -38,7 +38,7 @@ constexpr uint32_t kInactive = 0xFFFFFFFFu;
 constexpr uint32_t kSahMaxLevels = 1024;
 constexpr int kEmptyLo = 0x7f7fffff, kEmptyHi = (int)0x80800000;   // ordered-int FLT_MAX / -FLT_MAX (BuildWrapper.cu:170-171)
 constexpr uint32_t kBinWords = 13;        // p box [6], c box [6], count
-constexpr uint32_t kIdMask = 0x7FFFFFFFu; // bit 31 of an id: the leaf holds two triangles
+constexpr uint32_t kLeafMask = 0x7FFFFFFFu; // item_leaf: TrianglePair index | (two triangles ? 1 << 31 : 0)
 
 enum : uint32_t { kSahErrLocals = 0x100, kSahErrLevels = 0x200 };
 
@@ -48,7 +48,7 @@ struct SahSmall { uint32_t start, end, parent_idx, flags; };   // flags bit0 top
 
 struct SahHeader {
     int gp[6], gc[6];                  // scene primitive / centroid bounds, ordered ints
-    uint32_t status[8];                // [0] error flags, [1] number of leaves L
+    uint32_t status[8];                // [0] error flags, [1] number of items L, [2] leaf records, [3] split budget asked
     uint32_t small_count, pad[3];
     uint32_t cell_count[kSahCells], cell_start[kSahCells], cell_task[kSahCells];
     int cell_p[kSahCells][6], cell_c[kSahCells][6];
@@ -58,7 +58,8 @@ struct SahHeader {
 struct SahArgs {
     SahHeader* H;
     rt_node* nodes;
-    const float* aabbs;                // [n + 64][6]
+    const float* aabbs;                // [B + 64][6]
+    const uint32_t* item_leaf;         // [B]
     uint32_t* ids[2];
     uint32_t* task_of[2];
     uint8_t* binof;
@@ -68,7 +69,8 @@ struct SahArgs {
     uint32_t* chunk_hist;              // [chunk][2][8]
     uint32_t* chunk_prefix;            // [chunk]
     SahSmall* small;
-    uint32_t n, M;                     // triangles; positions = n + 64
+    uint32_t n, B, M;                  // triangles; B = upper bound of the item count (n, + n/5 with splits) = first
+                                       // top-tree position; positions M = B + 64
 };
 
 // ---- min / max on the ordered-int encoding (what the atomics compute)
@@ -106,11 +108,15 @@ __device__ __forceinline__ void load_box(const float* aabbs, uint32_t id, float*
 // written with count 0 as a marker and completed by sah_patch_top_kernel once the cell's sub-root exists
 __device__ __forceinline__ void sah_leaf_desc(const SahArgs& a, rt_node* out, uint32_t idv)
 {
-    const uint32_t id = idv & kIdMask;
+    const uint32_t id = idv;
     float b[6];
     load_box(a.aabbs, id, b);
-    if (id < a.n) sah_put_node(out, b, id, (idv >> 31) ? 2u : 1u, RT_CHILD_TRI);
-    else sah_put_node(out, b, id - a.n, 0u, RT_CHILD_BOX);
+    if (id < a.B) {
+        const uint32_t lv = a.item_leaf[id];
+        sah_put_node(out, b, lv & kLeafMask, (lv >> 31) ? 2u : 1u, RT_CHILD_TRI);
+    } else {
+        sah_put_node(out, b, id - a.B, 0u, RT_CHILD_BOX);
+    }
 }
 
 __device__ __forceinline__ int sah_axis(const float* c)   // SelectAxis (SharedTaskBuilder.cu:197-204)
@@ -124,7 +130,7 @@ __global__ void sah_init_kernel(SahHeader* H, rt_node* nodes, uint32_t n)
 {
     const uint32_t t = threadIdx.x;
     if (t < 6) { H->gp[t] = t < 3 ? kEmptyLo : kEmptyHi; H->gc[t] = t < 3 ? kEmptyLo : kEmptyHi; }
-    if (t < 8) H->status[t] = t == 1 ? n : 0u;
+    if (t < 8) H->status[t] = (t == 1 || t == 2) ? n : 0u;   // [1] items, [2] leaf records (overwritten by pairs / splits)
     if (t == 0) H->small_count = 0;
     if (t < kSahCells) {
         H->cell_count[t] = 0; H->cell_start[t] = 0; H->cell_task[t] = kInactive;
@@ -138,7 +144,7 @@ __global__ void sah_init_kernel(SahHeader* H, rt_node* nodes, uint32_t n)
 // Setup (Multiblock.cu:139-207): one thread per candidate (triangles 2k, 2k+1).  Leaf slot = input order.
 __global__ __launch_bounds__(256) void sah_setup_kernel(const float* __restrict__ f, uint32_t n,
                                                         rt_triangle_pair* __restrict__ leaves, float* __restrict__ aabbs,
-                                                        uint32_t* __restrict__ idsv, SahHeader* H,
+                                                        uint32_t* __restrict__ idsv, uint32_t* __restrict__ item_leaf, SahHeader* H,
                                                         const uint8_t* __restrict__ flags,
                                                         const uint32_t* __restrict__ block_offsets)
 {
@@ -209,7 +215,8 @@ __global__ __launch_bounds__(256) void sah_setup_kernel(const float* __restrict_
 #pragma unroll
             for (int j = 0; j < 3; j++) { u[j] = fmin_ord(ab[j], bb[j]); u[3 + j] = fmax_ord(ab[3 + j], bb[3 + j]); }
             bo[0] = make_float2(u[0], u[1]); bo[1] = make_float2(u[2], u[3]); bo[2] = make_float2(u[4], u[5]);
-            idsv[slot] = slot | 0x80000000u;
+            idsv[slot] = slot;
+            item_leaf[slot] = slot | 0x80000000u;
         } else {
             out[0] = make_uint4(__float_as_uint(A[0]), __float_as_uint(A[1]), __float_as_uint(A[2]), tid);
             out[1] = make_uint4(__float_as_uint(A[3]), __float_as_uint(A[4]), __float_as_uint(A[5]), 0u);
@@ -217,6 +224,7 @@ __global__ __launch_bounds__(256) void sah_setup_kernel(const float* __restrict_
             out[3] = make_uint4(__float_as_uint(A[6]), __float_as_uint(A[7]), __float_as_uint(A[8]), 0u);
             bo[0] = make_float2(ab[0], ab[1]); bo[1] = make_float2(ab[2], ab[3]); bo[2] = make_float2(ab[4], ab[5]);
             idsv[slot] = slot;
+            item_leaf[slot] = slot;
             if (second) {
                 out[4] = make_uint4(__float_as_uint(B[0]), __float_as_uint(B[1]), __float_as_uint(B[2]), tid + 1);
                 out[5] = make_uint4(__float_as_uint(B[3]), __float_as_uint(B[4]), __float_as_uint(B[5]), 0u);
@@ -224,6 +232,7 @@ __global__ __launch_bounds__(256) void sah_setup_kernel(const float* __restrict_
                 out[7] = make_uint4(__float_as_uint(B[6]), __float_as_uint(B[7]), __float_as_uint(B[8]), 0u);
                 bo[3] = make_float2(bb[0], bb[1]); bo[4] = make_float2(bb[2], bb[3]); bo[5] = make_float2(bb[4], bb[5]);
                 idsv[slot + 1] = slot + 1;
+                item_leaf[slot + 1] = slot + 1;
             }
         }
     }
@@ -232,6 +241,217 @@ __global__ __launch_bounds__(256) void sah_setup_kernel(const float* __restrict_
     if (threadIdx.x < 12) {
         int* g = threadIdx.x < 6 ? &H->gp[threadIdx.x] : &H->gc[threadIdx.x - 6];
         if ((threadIdx.x % 6) < 3) atomicMin(g, sb[threadIdx.x]); else atomicMax(g, sb[threadIdx.x]);
+    }
+}
+
+// ---- spatial splits: SetupSplits / SetupPairSplits (Multiblock.cu:209-425)
+// A leaf whose box spans several cells of the 4 x 4 x 4 grid over the SCENE box becomes one reference per cell, its box
+// clipped to the cell, while the running total of extra references stays below n / 5.  The reference takes that total
+// from an atomic counter (arrival order); here it is the prefix sum in input order, so three passes over the
+// candidates (2k, 2k+1): 0 = extra references wanted per workgroup, 1 = split decisions + references per workgroup,
+// 2 = write leaf records and references.  Exclusive scans of the workgroup sums in between (pair_scan_kernel).
+__device__ __forceinline__ void grid_cell(const float* p, const float* g, int* c)   // CalculateGridcell (Multiblock.cu:86-91)
+{
+#pragma unroll
+    for (int k = 0; k < 3; k++) c[k] = min(3, max(0, cvt_rzi(floorf((p[k] - g[k]) * 4.0f / (g[3 + k] - g[k])))));
+}
+__device__ __forceinline__ void cell_bounds(const int* c, const float* g, float* out)   // CellToBounds (Multiblock.cu:93-102)
+{
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float step = (g[3 + k] - g[k]) / 4.0f;
+        out[k] = g[k] + (float)c[k] * step;
+        out[3 + k] = g[k] + (float)(c[k] + 1) * step;
+    }
+}
+__device__ __forceinline__ void box_intersection(const float* a, const float* b, float* out)   // Common.cuh:269-272
+{
+#pragma unroll
+    for (int k = 0; k < 3; k++) { out[k] = fmax_ord(a[k], b[k]); out[3 + k] = fmin_ord(a[3 + k], b[3 + k]); }
+}
+__device__ __forceinline__ bool box_valid(const float* b) { return b[3] >= b[0] && b[4] >= b[1] && b[5] >= b[2]; }
+
+struct SplitPassArgs {
+    const float* tris;
+    uint32_t n, thresh;
+    const uint8_t* pair_flags;        // merge decision per candidate, or null (no pairs)
+    const uint32_t* pair_offsets;     // leaf-record slot of each workgroup's first candidate (pairs)
+    uint8_t* split_flags;             // bit s: leaf s of the candidate is split
+    uint32_t* sums_a;                 // pass 0 out / pass 1 in (scanned): extra references wanted
+    uint32_t* sums_b;                 // pass 1 out / pass 2 in (scanned): references written
+    rt_triangle_pair* leaves;
+    float* aabbs;
+    uint32_t* idsv;
+    uint32_t* item_leaf;
+    SahHeader* H;
+};
+
+template <int PASS>
+__global__ __launch_bounds__(256) void sah_split_pass_kernel(SplitPassArgs a)
+{
+    __shared__ uint32_t ws[8];
+    __shared__ int sb[6];
+    if (threadIdx.x < 6) sb[threadIdx.x] = threadIdx.x < 3 ? kEmptyLo : kEmptyHi;
+    __syncthreads();
+    float grid[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) grid[k] = ordered_int_to_float(a.H->gp[k]);
+    int cmin[3] = {kEmptyLo, kEmptyLo, kEmptyLo}, cmax[3] = {kEmptyHi, kEmptyHi, kEmptyHi};   // centroid bounds (pass 2)
+    const uint32_t ntiles = ((a.n + 1) / 2 + 255) / 256;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t k = tile * 256 + threadIdx.x, tid = 2 * k;
+        const bool live = tid < a.n, second = tid + 1 < a.n;
+        const bool merge = live && a.pair_flags && a.pair_flags[k] != 0;
+        const uint32_t nleaf = live ? (merge ? 1u : 1u + (second ? 1u : 0u)) : 0u;
+        float A[9], Bv[9], box[2][6];
+        int lo[2][3], hi[2][3];
+        uint32_t extra[2] = {0, 0};
+        bool want[2] = {false, false};
+        if (live) {
+            load_tri9(a.tris + (size_t)tid * 9, A);
+            load_tri9(a.tris + (size_t)(second ? tid + 1 : tid) * 9, Bv);
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                box[0][j] = fminf(fminf(A[j], A[3 + j]), A[6 + j]); box[0][3 + j] = fmaxf(fmaxf(A[j], A[3 + j]), A[6 + j]);
+                box[1][j] = fminf(fminf(Bv[j], Bv[3 + j]), Bv[6 + j]); box[1][3 + j] = fmaxf(fmaxf(Bv[j], Bv[3 + j]), Bv[6 + j]);
+            }
+        }
+        float ab[6], bb[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) { ab[j] = box[0][j]; bb[j] = box[1][j]; }
+        if (merge) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) { box[0][j] = fmin_ord(ab[j], bb[j]); box[0][3 + j] = fmax_ord(ab[3 + j], bb[3 + j]); }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            if ((uint32_t)s < nleaf) {
+                grid_cell(&box[s][0], grid, lo[s]);
+                grid_cell(&box[s][3], grid, hi[s]);
+                want[s] = lo[s][0] != hi[s][0] || lo[s][1] != hi[s][1] || lo[s][2] != hi[s][2];
+                extra[s] = want[s] ? (uint32_t)((hi[s][0] - lo[s][0] + 1) * (hi[s][1] - lo[s][1] + 1) * (hi[s][2] - lo[s][2] + 1) - 1) : 0u;
+            }
+        }
+        uint32_t total;
+        if (PASS == 0) {
+            block_excl_scan_u32<256>(extra[0] + extra[1], ws, &total);
+            if (threadIdx.x == 0) a.sums_a[tile] = total;
+            continue;
+        }
+        // the extra_leaves counter before this candidate: every leaf that WANTS a split adds to it, granted or not
+        const uint32_t before = a.sums_a[tile] + block_excl_scan_u32<256>(extra[0] + extra[1], ws, &total);
+        bool split[2];
+        split[0] = want[0] && before + extra[0] < a.thresh;
+        split[1] = want[1] && before + extra[0] + extra[1] < a.thresh;
+        uint32_t refs[2] = {0, 0};
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            if ((uint32_t)s >= nleaf) continue;
+            refs[s] = 1;
+            if (split[s]) {
+                refs[s] = extra[s] + 1;
+                if (merge) {   // cells neither triangle's box overlaps are dropped (Multiblock.cu:362-373)
+                    refs[s] = 0;
+                    int c[3];
+                    for (c[2] = lo[s][2]; c[2] <= hi[s][2]; c[2]++)
+                        for (c[1] = lo[s][1]; c[1] <= hi[s][1]; c[1]++)
+                            for (c[0] = lo[s][0]; c[0] <= hi[s][0]; c[0]++) {
+                                float cb[6], ia[6], ib[6];
+                                cell_bounds(c, grid, cb);
+                                box_intersection(ab, cb, ia);
+                                box_intersection(bb, cb, ib);
+                                refs[s] += (box_valid(ia) || box_valid(ib)) ? 1u : 0u;
+                            }
+                }
+            }
+        }
+        if (PASS == 1) {
+            if (live) a.split_flags[k] = (uint8_t)((split[0] ? 1 : 0) | (split[1] ? 2 : 0));
+            block_excl_scan_u32<256>(refs[0] + refs[1], ws, &total);
+            if (threadIdx.x == 0) a.sums_b[tile] = total;
+            continue;
+        }
+        // ---- pass 2: leaf records and references
+        uint32_t idx = a.sums_b[tile] + block_excl_scan_u32<256>(refs[0] + refs[1], ws, &total);
+        uint32_t rec = tid;   // leaf-record slot: the triangle index, or the pair prefix sum
+        if (a.pair_flags) rec = a.pair_offsets[tile] + block_excl_scan_u32<256>(nleaf, ws, &total);
+        if (!live) continue;
+        uint4* out = reinterpret_cast<uint4*>(a.leaves + rec);
+        if (merge) {
+            int ra = 0, rb = 0;
+            can_form_pair(A, Bv, ra, rb);
+            float r[9], v3[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                r[j] = ra == 1 ? A[6 + j] : (ra == 2 ? A[3 + j] : A[j]);
+                r[3 + j] = ra == 1 ? A[j] : (ra == 2 ? A[6 + j] : A[3 + j]);
+                r[6 + j] = ra == 1 ? A[3 + j] : (ra == 2 ? A[j] : A[6 + j]);
+                v3[j] = rb == 2 ? Bv[j] : (rb == 1 ? Bv[3 + j] : Bv[6 + j]);
+            }
+            out[0] = make_uint4(__float_as_uint(r[0]), __float_as_uint(r[1]), __float_as_uint(r[2]), tid);
+            out[1] = make_uint4(__float_as_uint(r[3]), __float_as_uint(r[4]), __float_as_uint(r[5]), tid + 1);
+            out[2] = make_uint4(__float_as_uint(r[6]), __float_as_uint(r[7]), __float_as_uint(r[8]), (uint32_t)ra | ((uint32_t)rb << 16));
+            out[3] = make_uint4(__float_as_uint(v3[0]), __float_as_uint(v3[1]), __float_as_uint(v3[2]), 0u);
+        } else {
+            out[0] = make_uint4(__float_as_uint(A[0]), __float_as_uint(A[1]), __float_as_uint(A[2]), tid);
+            out[1] = make_uint4(__float_as_uint(A[3]), __float_as_uint(A[4]), __float_as_uint(A[5]), 0u);
+            out[2] = make_uint4(__float_as_uint(A[6]), __float_as_uint(A[7]), __float_as_uint(A[8]), 0u);
+            out[3] = make_uint4(__float_as_uint(A[6]), __float_as_uint(A[7]), __float_as_uint(A[8]), 0u);
+            if (second) {
+                out[4] = make_uint4(__float_as_uint(Bv[0]), __float_as_uint(Bv[1]), __float_as_uint(Bv[2]), tid + 1);
+                out[5] = make_uint4(__float_as_uint(Bv[3]), __float_as_uint(Bv[4]), __float_as_uint(Bv[5]), 0u);
+                out[6] = make_uint4(__float_as_uint(Bv[6]), __float_as_uint(Bv[7]), __float_as_uint(Bv[8]), 0u);
+                out[7] = make_uint4(__float_as_uint(Bv[6]), __float_as_uint(Bv[7]), __float_as_uint(Bv[8]), 0u);
+            }
+        }
+        for (uint32_t s = 0; s < nleaf; s++) {
+            const uint32_t leafv = (rec + s) | (merge ? 0x80000000u : 0u);
+            const float* bx = s ? box[1] : box[0];
+            const int* l3 = s ? lo[1] : lo[0];
+            const int* h3 = s ? hi[1] : hi[0];
+            const bool sp = s ? split[1] : split[0];
+            auto emit = [&](const float* o) {
+                float2* bo = reinterpret_cast<float2*>(a.aabbs + (size_t)idx * 6);
+                bo[0] = make_float2(o[0], o[1]); bo[1] = make_float2(o[2], o[3]); bo[2] = make_float2(o[4], o[5]);
+                a.idsv[idx] = idx;
+                a.item_leaf[idx] = leafv;
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const int ctr = float_to_ordered_int((o[j] + o[3 + j]) * 0.5f);
+                    cmin[j] = min(cmin[j], ctr); cmax[j] = max(cmax[j], ctr);
+                }
+                idx++;
+            };
+            if (!sp) { emit(bx); continue; }
+            int c[3];
+            for (c[2] = l3[2]; c[2] <= h3[2]; c[2]++)
+                for (c[1] = l3[1]; c[1] <= h3[1]; c[1]++)
+                    for (c[0] = l3[0]; c[0] <= h3[0]; c[0]++) {
+                        float cb[6], o[6];
+                        cell_bounds(c, grid, cb);
+                        if (merge) {
+                            float ia[6], ib[6];
+                            box_intersection(ab, cb, ia);
+                            box_intersection(bb, cb, ib);
+                            if (!box_valid(ia) && !box_valid(ib)) continue;
+#pragma unroll
+                            for (int j = 0; j < 3; j++) { o[j] = fmin_ord(ia[j], ib[j]); o[3 + j] = fmax_ord(ia[3 + j], ib[3 + j]); }
+                        } else {
+                            box_intersection(bx, cb, o);
+                        }
+                        emit(o);
+                    }
+        }
+    }
+    if (PASS == 2) {
+        // centroid bounds of the references: registers -> wave -> LDS -> 6 global atomics per workgroup
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int l = wave_min_i32(cmin[j]), h = wave_max_i32(cmax[j]);
+            if ((threadIdx.x & 63) == 0) { atomicMin(&sb[j], l); atomicMax(&sb[3 + j], h); }
+        }
+        __syncthreads();
+        if (threadIdx.x < 6) { if (threadIdx.x < 3) atomicMin(&a.H->gc[threadIdx.x], sb[threadIdx.x]); else atomicMax(&a.H->gc[threadIdx.x], sb[threadIdx.x]); }
     }
 }
 
@@ -335,10 +555,10 @@ __global__ __launch_bounds__(128) void sah_roots_kernel(SahArgs a, const uint32_
         H->cell_start[t] = start;
         float pb[6], cb[6];
         for (int j = 0; j < 6; j++) { pb[j] = ordered_int_to_float(H->cell_p[t][j]); cb[j] = ordered_int_to_float(H->cell_c[t][j]); }
-        for (int j = 0; j < 6; j++) aabbs_w[(size_t)(a.n + t) * 6 + j] = pb[j];
+        for (int j = 0; j < 6; j++) aabbs_w[(size_t)(a.B + t) * 6 + j] = pb[j];
         uint32_t task = kInactive;
         if (cnt) {
-            a.ids[0][a.n + k] = a.n + t;
+            a.ids[0][a.B + k] = a.B + t;
             const uint32_t parent = 2 * kSahCells + 2 * start;
             reinterpret_cast<uint4*>(a.nodes + parent + 1)[0] = make_uint4(0, 0, 0, 0);   // the root's sibling slot: None
             reinterpret_cast<uint4*>(a.nodes + parent + 1)[1] = make_uint4(0, 0, 0, 0);
@@ -363,23 +583,23 @@ __global__ __launch_bounds__(128) void sah_roots_kernel(SahArgs a, const uint32_
             task = atomicAdd(&H->level_count[0], 1u);
             SahTask T;
             for (int j = 0; j < 6; j++) { T.c[j] = ordered_int_to_float(H->gc[j]); T.p[j] = ordered_int_to_float(H->gp[j]); }
-            T.start = a.n; T.end = a.n + K; T.parent_idx = 0; T.flags = 1;
+            T.start = a.B; T.end = a.B + K; T.parent_idx = 0; T.flags = 1;
             a.tasks[0][task] = T;
             sah_init_bins(a.bins[0], task, 0, 1);
         } else if (K) {
             const uint32_t s = atomicAdd(&H->small_count, 1u);
-            a.small[s] = SahSmall{a.n, a.n + K, 0u, 1u | 4u};
+            a.small[s] = SahSmall{a.B, a.B + K, 0u, 1u | 4u};
         }
-        for (uint32_t j = 0; j < kSahCells; j++) a.task_of[0][a.n + j] = j < K ? task : kInactive;
+        for (uint32_t j = 0; j < kSahCells; j++) a.task_of[0][a.B + j] = j < K ? task : kInactive;
     }
 }
 
 // position -> root task of its cell (the sorted keys of the distribution pass are the cell ids)
 __global__ __launch_bounds__(256) void sah_assign_kernel(SahArgs a, const uint32_t* n_dev)
 {
-    const uint32_t L = n_dev ? *n_dev : a.n;
+    const uint32_t L = n_dev ? *n_dev : a.B;
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.n) return;
+    if (i >= a.B) return;
     a.task_of[0][i] = i < L ? a.H->cell_task[a.task_of[0][i] & (kSahCells - 1)] : kInactive;
 }
 
@@ -427,7 +647,7 @@ __global__ __launch_bounds__(256) void sah_bin_kernel(SahArgs a, uint32_t lvl)
             const float cmin = axis == 0 ? c[0] : (axis == 1 ? c[1] : c[2]);
             const float cmax = axis == 0 ? c[3] : (axis == 1 ? c[4] : c[5]);
             const float k1 = 8 * (1 - epsilon) / (cmax - cmin);
-            const uint32_t id = a.ids[cur][pos] & kIdMask;
+            const uint32_t id = a.ids[cur][pos];
             float b[6];
             load_box(a.aabbs, id, b);
             float ctr[3];
@@ -523,7 +743,7 @@ __global__ __launch_bounds__(kSplitWaves * 64) void sah_split_kernel(SahArgs a, 
     SahTask T = {};
     if (valid) T = a.tasks[cur][w];
     const uint32_t count = T.end - T.start;
-    const int bias = (T.flags & 1u) ? -2 * (int)a.n : (int)(2 * kSahCells);
+    const int bias = (T.flags & 1u) ? -2 * (int)a.B : (int)(2 * kSahCells);
 
     int cb[2][12];   // child boxes, ordered ints: [side][p box 6, c box 6]
 #pragma unroll
@@ -586,7 +806,7 @@ __global__ __launch_bounds__(kSplitWaves * 64) void sah_split_kernel(SahArgs a, 
             for (int k = 0; k < 12; k++) v[s][k] = (k % 6) < 3 ? kEmptyLo : kEmptyHi;
         for (uint32_t i = ts + lane; i < te; i += 64) {
             float b[6];
-            load_box(a.aabbs, a.ids[cur][i] & kIdMask, b);
+            load_box(a.aabbs, a.ids[cur][i], b);
             const bool right = i >= tm;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
@@ -728,14 +948,14 @@ __global__ __launch_bounds__(kSmallWaves * 64) void sah_small_kernel(SahArgs a, 
     const SahSmall R = a.small[task];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t cnt = R.end - R.start, base = R.start;
-    const int bias = (R.flags & 1u) ? -2 * (int)a.n : (int)(2 * kSahCells);
+    const int bias = (R.flags & 1u) ? -2 * (int)a.B : (int)(2 * kSahCells);
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 
     uint32_t idv = 0;
     float b[6] = {0, 0, 0, 0, 0, 0};
     if (lane < cnt) {
         idv = a.ids[(R.flags >> 1) & 1u][base + lane];
-        load_box(a.aabbs, idv & kIdMask, b);
+        load_box(a.aabbs, idv, b);
     }
     uint32_t s = 0, e = cnt, parent = R.parent_idx;
     bool active = lane < cnt;
@@ -889,9 +1109,10 @@ __global__ __launch_bounds__(kSmallWaves * 64) void sah_small_kernel(SahArgs a, 
 
 // top-tree leaves: copy child / count / type of the cell's sub-root (SharedTaskBuilder.cu:422-446; the reference
 // forces type Box, which breaks a cell that holds a single leaf -- the type is copied here)
-__global__ void sah_patch_top_kernel(SahArgs a)
+__global__ void sah_patch_top_kernel(SahArgs a, int records_in_status2)
 {
     const uint32_t s = threadIdx.x;
+    if (s == 0 && !records_in_status2) a.H->status[2] = a.H->status[1];   // without splits: one item per leaf record
     if (s >= 2 * kSahCells) return;
     rt_node* nd = a.nodes + s;
     if ((nd->w28 >> 29) != RT_CHILD_BOX || (nd->w12 >> 29) != 0) return;
@@ -905,7 +1126,8 @@ __global__ void sah_patch_top_kernel(SahArgs a)
 SahLayout sah_layout(uint32_t n)
 {
     SahLayout L;
-    const size_t M = (size_t)n + kSahCells;
+    const size_t B = (size_t)n + n / 5;          // items with --splits: n leaves + fewer than n/5 extra references
+    const size_t M = B + kSahCells;
     const size_t TA = M / (kSahSmall + 1) + 2;
     const size_t chunks = (M + kSahChunk - 1) / kSahChunk;
     auto al = [](size_t v) { return (v + 255) / 256 * 256; };
@@ -917,6 +1139,7 @@ SahLayout sah_layout(uint32_t n)
     L.task_of0 = off;     off = al(off + M * 4);
     L.task_of1 = off;     off = al(off + M * 4);
     L.binof = off;        off = al(off + M);
+    L.item_leaf = off;    off = al(off + B * 4 + 4);
     L.tasks0 = off;       off = al(off + TA * sizeof(SahTask));
     L.tasks1 = off;       off = al(off + TA * sizeof(SahTask));
     L.splits = off;       off = al(off + TA * sizeof(SahSplit));
@@ -925,17 +1148,20 @@ SahLayout sah_layout(uint32_t n)
     L.chunk_hist = off;   off = al(off + chunks * 16 * 4);
     L.chunk_prefix = off; off = al(off + chunks * 4);
     L.small = off;        off = al(off + M * sizeof(SahSmall));
-    L.sort = off;         off = al(off + sort_scratch_layout(n).total);
+    L.sort = off;         off = al(off + sort_scratch_layout((uint32_t)B).total);
     L.pair_flags = off;   off = al(off + ((size_t)n + 1) / 2 + 1);
     L.pair_sums = off;    off = al(off + (((size_t)n + 1) / 2 / 256 + 2) * 4);
+    L.split_flags = off;  off = al(off + ((size_t)n + 1) / 2 + 1);
+    L.split_sums_a = off; off = al(off + (((size_t)n + 1) / 2 / 256 + 2) * 4);
+    L.split_sums_b = off; off = al(off + (((size_t)n + 1) / 2 / 256 + 2) * 4);
     L.status = L.header + offsetof(SahHeader, status);
     L.cell_counts = L.header + offsetof(SahHeader, cell_count);
     L.total = off;
     return L;
 }
 
-hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, rt_triangle_pair* leaves, rt_node* nodes,
-                            void* scratch, hipStream_t st, uint32_t* levels_run)
+hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, bool splits, rt_triangle_pair* leaves,
+                            rt_node* nodes, void* scratch, hipStream_t st, uint32_t* levels_run)
 {
     const SahLayout L = sah_layout(n);
     char* s = static_cast<char*>(scratch);
@@ -943,7 +1169,9 @@ hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, rt_
     a.H = reinterpret_cast<SahHeader*>(s + L.header);
     a.nodes = nodes;
     float* aabbs = reinterpret_cast<float*>(s + L.aabbs);
+    uint32_t* item_leaf = reinterpret_cast<uint32_t*>(s + L.item_leaf);
     a.aabbs = aabbs;
+    a.item_leaf = item_leaf;
     a.ids[0] = reinterpret_cast<uint32_t*>(s + L.ids0);
     a.ids[1] = reinterpret_cast<uint32_t*>(s + L.ids1);
     a.task_of[0] = reinterpret_cast<uint32_t*>(s + L.task_of0);
@@ -958,30 +1186,56 @@ hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, rt_
     a.chunk_prefix = reinterpret_cast<uint32_t*>(s + L.chunk_prefix);
     a.small = reinterpret_cast<SahSmall*>(s + L.small);
     a.n = n;
-    a.M = n + kSahCells;
-    uint32_t* num_leaves = &a.H->status[1];
-    const uint32_t* n_dev = pairs ? num_leaves : nullptr;
+    a.B = n + (splits ? n / 5 : 0);      // host-known upper bound of the item count; the top tree's items start here
+    a.M = a.B + kSahCells;
+    uint32_t* num_items = &a.H->status[1];
+    uint32_t* num_records = &a.H->status[2];
+    const uint32_t* n_dev = (pairs || splits) ? num_items : nullptr;
     if (levels_run) *levels_run = 0;
 
     sah_init_kernel<<<1, 256, 0, st>>>(a.H, nodes, n);
     if (n == 0) return hipGetLastError();
     const uint32_t cand = (n + 1) / 2, cblocks = (cand + 255) / 256;
+    const uint32_t pblocks = cblocks < 256 ? cblocks : 256;
     uint8_t* pflags = nullptr;
     uint32_t* psums = nullptr;
+    hipError_t e = hipSuccess;
     if (pairs) {
         pflags = reinterpret_cast<uint8_t*>(s + L.pair_flags);
         psums = reinterpret_cast<uint32_t*>(s + L.pair_sums);
-        hipError_t e = launch_pair_slots(tris, n, pflags, psums, num_leaves, st);
+        e = launch_pair_slots(tris, n, pflags, psums, splits ? num_records : num_items, st);
         if (e != hipSuccess) return e;
     }
-    sah_setup_kernel<<<cblocks < 256 ? cblocks : 256, 256, 0, st>>>(reinterpret_cast<const float*>(tris), n, leaves, aabbs, a.ids[1], a.H, pflags, psums);
-    sah_grid_kernel<<<(n + 255) / 256 < 256 ? (n + 255) / 256 : 256, 256, 0, st>>>(aabbs, n, n_dev, a.H, a.task_of[1]);
+    if (splits) {
+        // SetupSplits / SetupPairSplits after CalculateSceneAabb (BuildWrapper.cu:188-210)
+        e = launch_scene_aabb(tris, n, a.H->gp, st);
+        if (e != hipSuccess) return e;
+        SplitPassArgs sp;
+        sp.tris = reinterpret_cast<const float*>(tris);
+        sp.n = n; sp.thresh = n / 5;
+        sp.pair_flags = pflags; sp.pair_offsets = psums;
+        sp.split_flags = reinterpret_cast<uint8_t*>(s + L.split_flags);
+        sp.sums_a = reinterpret_cast<uint32_t*>(s + L.split_sums_a);
+        sp.sums_b = reinterpret_cast<uint32_t*>(s + L.split_sums_b);
+        sp.leaves = leaves; sp.aabbs = aabbs; sp.idsv = a.ids[1]; sp.item_leaf = item_leaf; sp.H = a.H;
+        sah_split_pass_kernel<0><<<pblocks, 256, 0, st>>>(sp);
+        e = launch_block_scan(sp.sums_a, cblocks, &a.H->status[3], st);
+        if (e != hipSuccess) return e;
+        sah_split_pass_kernel<1><<<pblocks, 256, 0, st>>>(sp);
+        e = launch_block_scan(sp.sums_b, cblocks, num_items, st);
+        if (e != hipSuccess) return e;
+        sah_split_pass_kernel<2><<<pblocks, 256, 0, st>>>(sp);
+    } else {
+        sah_setup_kernel<<<pblocks, 256, 0, st>>>(reinterpret_cast<const float*>(tris), n, leaves, aabbs, a.ids[1], item_leaf, a.H, pflags, psums);
+    }
+    const uint32_t iblocks = (a.B + 255) / 256;
+    sah_grid_kernel<<<iblocks < 256 ? iblocks : 256, 256, 0, st>>>(aabbs, a.B, n_dev, a.H, a.task_of[1]);
     // GridBlockDistribute: cell members in ascending leaf index = one stable radix pass on the cell id
     uint32_t* digit_total = nullptr;
-    hipError_t e = launch_radix_pass(a.task_of[1], a.ids[1], a.task_of[0], a.ids[0], n, 0, s + L.sort, st, n_dev, &digit_total);
+    e = launch_radix_pass(a.task_of[1], a.ids[1], a.task_of[0], a.ids[0], a.B, 0, s + L.sort, st, n_dev, &digit_total);
     if (e != hipSuccess) return e;
     sah_roots_kernel<<<1, 128, 0, st>>>(a, digit_total, aabbs);
-    sah_assign_kernel<<<(n + 255) / 256, 256, 0, st>>>(a, n_dev);
+    sah_assign_kernel<<<iblocks, 256, 0, st>>>(a, n_dev);
 
     const uint32_t chunks = (a.M + kSahChunk - 1) / kSahChunk;
     const uint32_t TA = a.M / (kSahSmall + 1) + 2;
@@ -990,7 +1244,7 @@ hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, rt_
     // levels until every task has <= kSahSmall items: about log2(items per cell / kSahSmall) when the splits are
     // balanced; the first batch adds a margin, later batches are short
     uint32_t batch = 3;
-    for (uint32_t per_cell = n / kSahCells; per_cell > kSahSmall; per_cell >>= 1) batch++;
+    for (uint32_t per_cell = a.B / kSahCells; per_cell > kSahSmall; per_cell >>= 1) batch++;
     uint32_t nsmall = 0;
     while (true) {
         for (uint32_t i = 0; i < batch && lvl + 1 < kSahMaxLevels; i++, lvl++) {
@@ -1014,7 +1268,7 @@ hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, rt_
     }
     if (levels_run) *levels_run = lvl;
     if (nsmall) sah_small_kernel<<<(nsmall + kSmallWaves - 1) / kSmallWaves, kSmallWaves * 64, 0, st>>>(a, nsmall);
-    sah_patch_top_kernel<<<1, 128, 0, st>>>(a);
+    sah_patch_top_kernel<<<1, 128, 0, st>>>(a, splits ? 1 : 0);
     return hipGetLastError();
 }
 

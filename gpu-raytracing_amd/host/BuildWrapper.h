@@ -19,6 +19,6 @@ size_t BuMemoryRequirements(uint32_t num_triangles);                       // Bu
 // synchronises after every kernel through its run() macro).  Error convention of the reference: message + exit.
 void RunBottomUpBuild(BuildInput input, Arguments args, bool hybrid, void* stream = nullptr);  // BuildWrapper.cu:253-362
 size_t SahMemoryRequirements(uint32_t num_triangles);                      // BuildWrapper.cu:126-130
-// SAH build without spatial splits (args.enable_splits -> "unsupported", exit).  Trace root = (0, 1) (main.cu:222-223).
+// SAH build (args.enable_pairs, args.enable_splits as in the reference).  Trace root = (0, 1) (main.cu:222-223).
 // Synchronises `stream`: the number of build levels is data dependent (the reference syncs too, BuildWrapper.cu:229).
 void RunSahBuild(BuildInput input, Arguments args, void* stream = nullptr);  // BuildWrapper.cu:140-251

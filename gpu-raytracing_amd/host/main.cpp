@@ -103,7 +103,7 @@ int main(int argc, char** argv)
     const unsigned root_index = hybrid ? (num_leaves * 2 > 2 ? num_leaves * 2 : 2) + 1 : 0;
     if (args.enable_pairs) printf("  leaves after pairing: %u of %u triangles\n", num_leaves, n);
 
-    std::vector<Node> nodes(sah ? (size_t)n * 2 + 130 : (size_t)(n ? n : 1) * 4);   // SAH: top tree [0, 128) + 2L cell-tree slots
+    std::vector<Node> nodes(sah ? ((size_t)n + n / 5) * 2 + 130 : (size_t)(n ? n : 1) * 4);   // SAH: top tree [0, 128) + 2L slots, L < n + n/5
     check(hipMemcpy(nodes.data(), in.nodes_out, sizeof(Node) * nodes.size(), hipMemcpyDeviceToHost));
     const HierarchyStats hs = CountNodes(nodes.data(), root_index, root_count);
     printf("Hierarchy Stats:\n  num nodes: %d\n  num tree nodes: %d\n  num leaf nodes: %d\n", hs.numNodes, hs.numTreeNodes, hs.numLeafNodes);

@@ -110,7 +110,7 @@ typedef struct rt_scene {
 enum {
     RT_OK = 0,
     RT_ERR_INVALID_ARGUMENT = -1,
-    RT_ERR_UNSUPPORTED = -2,       /* spatial splits (--splits): SURVEY 8(f) rank 3, second half */
+    RT_ERR_UNSUPPORTED = -2,       /* (no option of the built paths returns it any more; kept for ABI stability) */
     RT_ERR_TOO_LARGE = -3,         /* n exceeds the 29-bit child index of Node (Common.cuh:152-159) */
     RT_ERR_HIP_BASE = -1000        /* -(hipError_t) + RT_ERR_HIP_BASE */
 };
@@ -138,8 +138,11 @@ size_t rt_sah_memory_requirements(uint32_t num_triangles);
  * by centroid (Setup, GridBlockCounts/Scan/Distribute, Multiblock.cu:139-207,427-546), one binned-SAH sub-tree per
  * cell and a SAH top tree over the cells (SharedTaskBuild, SharedTaskBuilder.cu:93-607,909-967).  Trace root =
  * (slot 0, count 1) (main.cu:222-223).  input->scratch holds rt_sah_memory_requirements(n) bytes, nodes_out
- * rt_nodes_bytes(n); the tree uses slots [0, 128 + 2L).  args->enable_pairs as in rt_run_bottom_up_build;
- * args->enable_splits (SetupSplits / SetupPairSplits) -> RT_ERR_UNSUPPORTED.
+ * rt_nodes_bytes(n); the tree uses slots [0, 128 + 2L), L = number of items.  args->enable_pairs as in
+ * rt_run_bottom_up_build.  args->enable_splits (SetupSplits / SetupPairSplits, Multiblock.cu:209-425): a leaf whose
+ * box spans several cells of the 4x4x4 grid over the scene box is referenced once per cell, box clipped to the cell,
+ * while the running total of extra references -- taken in input order; an atomic counter in the reference -- stays
+ * below n/5 (so L < n + n/5; n <= 2^25 with splits).
  * Same tree as the reference up to numbering, which is deterministic here: leaf slots in input order, node slots
  * = f(split position) (see gpu-raytracing_amd/csrc/sah_build.hip).  The number of build levels is data dependent:
  * like the reference (cudaMemcpy of num_leaves, BuildWrapper.cu:229) this call synchronises `stream`. */
@@ -147,8 +150,9 @@ int rt_run_sah_build(const rt_build_input* input, const rt_arguments* args, void
 
 typedef struct rt_sah_scratch_layout {
     size_t p_aabb, c_aabb;  /* int32[6] each: ordered-int primitive / centroid bounds of the scene (BuildWrapper.cu:170-176) */
-    size_t status;          /* uint32[8]: [0] error flags of the last build (0 = ok), [1] number of leaves L */
-    size_t num_leaves;      /* = status + 4 */
+    size_t status;          /* uint32[8]: [0] error flags of the last build (0 = ok), [1] number of items L (leaves, or
+                             * leaf references with splits), [2] number of TrianglePair records written */
+    size_t num_leaves;      /* = status + 4 (items) */
     size_t cell_counts;     /* uint32[64]: leaves per grid cell (block_counts, Multiblock.cu:427) */
     size_t total;
 } rt_sah_scratch_layout;

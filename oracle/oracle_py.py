@@ -127,20 +127,23 @@ def build_hybrid(tris: np.ndarray) -> dict:
     return b
 
 
-def build_sah(tris: np.ndarray, pairs: bool = False) -> dict:
-    """RunSahBuild (no spatial splits), deterministic restatement.  Trace root = (0, 1) (main.cu:222-223).
-    nodes: the 2*64 + 2L slots in use (top tree in [0, 128), cell trees above)."""
+def build_sah(tris: np.ndarray, pairs: bool = False, splits: bool = False) -> dict:
+    """RunSahBuild, deterministic restatement.  Trace root = (0, 1) (main.cu:222-223).
+    nodes: the 2*64 + 2L slots in use (top tree in [0, 128), cell trees above); L = items (leaves, or leaf references
+    with splits); leaves: the R TrianglePair records."""
     t = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1, 9)
     n = t.shape[0]
-    nodes = np.zeros(128 + 2 * n + 2, dtype=NODE)
+    nodes = np.zeros(128 + 2 * (n + n // 5) + 2, dtype=NODE)
     leaves = np.zeros(max(n, 1), dtype=TRIANGLE_PAIR)
     cells = np.zeros(64, np.uint32)
+    nrec = np.zeros(1, np.uint32)
     L = lib()
     L.ora_build_sah.restype = ctypes.c_uint32
-    L.ora_build_sah.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
-                                ctypes.c_void_p]
-    nl = int(L.ora_build_sah(_p(t), n, int(bool(pairs)), _p(nodes), _p(leaves), _p(cells)))
-    return dict(nodes=nodes[:128 + 2 * nl], leaves=leaves[:nl], n=n, L=nl, root=0, count=1, cell_counts=cells)
+    L.ora_build_sah.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    nl = int(L.ora_build_sah(_p(t), n, int(bool(pairs)), int(bool(splits)), _p(nodes), _p(leaves), _p(cells), _p(nrec)))
+    return dict(nodes=nodes[:128 + 2 * nl], leaves=leaves[:int(nrec[0])], n=n, L=nl, R=int(nrec[0]), root=0, count=1,
+                cell_counts=cells)
 
 
 def count_nodes(nodes: np.ndarray, root: int, count: int) -> tuple:

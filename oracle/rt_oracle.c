@@ -670,10 +670,11 @@ uint32_t ora_build_hybrid_top(ora_node* nodes, uint32_t L, const int32_t aabb[6]
  * kernels (gpu-raytracing_amd/csrc/sah_build.hip):
  *   - leaf slot = input order (prefix sum of the per-candidate leaf counts with pairs on);
  *   - cell members in ascending leaf index; non-empty cells in ascending cell index; partitions are stable;
- *   - item positions: leaves occupy positions [0, L) of the id array (cell b = [start_b, end_b)), the top tree's
- *     items (cells) positions [n, n+K) (n = number of input triangles >= L, known on the host with pairs on);
+ *   - item positions: the L items (leaves, or leaf references with splits) occupy positions [0, L) of the id array
+ *     (cell b = [start_b, end_b)), the top tree's items (cells) positions [B, B+K), B = n (+ n/5 with splits): the
+ *     host-known upper bound of L;
  *   - node slots: the two child slots of a split between positions mid-1 | mid (or of a 2-item leaf group at
- *     start, start+1 -> mid = start+1) sit at BIAS + 2*mid, BIAS = 128 for the cell trees and -2n for the top tree
+ *     start, start+1 -> mid = start+1) sit at BIAS + 2*mid, BIAS = 128 for the cell trees and -2B for the top tree
  *     (so the top tree lives in slots [0, 128), like the reference's 2*NUM_BLOCKS offset); the root descriptor of
  *     cell b is slot 128 + 2*start_b (its sibling slot is unused, type None), the top root is slot 0.  Every slot
  *     is written exactly once, independent of processing order.
@@ -722,17 +723,18 @@ static inline void box_centre(const float* b, float* c) { for (int k = 0; k < 3;
 typedef struct {
     ora_node* nodes;
     const float (*aabbs)[6];      /* item boxes: [0, L) leaves, [n, n+64) cells */
-    uint32_t* ids[2];             /* item ids per position (bit 31: the leaf holds two triangles) */
-    uint32_t L;                   /* here: n, the first cell item */
+    uint32_t* ids[2];             /* item ids per position */
+    uint32_t L;                   /* top_base: the first cell item (>= number of leaf items) */
     const uint32_t* cell_start;   /* top tree leaves point at the cell sub-roots */
+    const uint32_t* item_leaf;    /* leaf item -> TrianglePair index | (two triangles ? 1u << 31 : 0) */
 } sah_ctx;
 typedef struct { uint32_t start, end, parent_idx, buf; float c[6]; int has_c; } sah_task;
 
 static void sah_leaf_desc(const sah_ctx* x, ora_node* out, uint32_t idv)
 {
-    const uint32_t id = idv & 0x7FFFFFFFu;
+    const uint32_t id = idv;
     if (id < x->L) {                                          /* (:405-421) leaf_type Tri */
-        put_node(out, x->aabbs[id], id, (idv >> 31) ? 2 : 1, ORA_TYPE_TRI);
+        put_node(out, x->aabbs[id], x->item_leaf[id] & 0x7FFFFFFFu, (x->item_leaf[id] >> 31) ? 2 : 1, ORA_TYPE_TRI);
     } else {                                                  /* top_of_tree (:422-446): copy the cell's sub-root */
         const ora_node* sub = &x->nodes[2 * SAH_CELLS + 2 * x->cell_start[id - x->L]];
         put_node(out, x->aabbs[id], sub->w28 & NODE_PARENT_MASK, sub->w12 >> 29, sub->w28 >> 29);
@@ -755,7 +757,7 @@ static void sah_build_range(const sah_ctx* x, sah_task root, int64_t bias)
         ibox pi; ibox_reset(&pi);
         ibox ci; ibox_reset(&ci);
         for (uint32_t i = t.start; i < t.end; i++) {
-            const float* bx = x->aabbs[in[i] & 0x7FFFFFFFu];
+            const float* bx = x->aabbs[in[i]];
             float ctr[3]; box_centre(bx, ctr);
             ibox_grow_box(&pi, bx);
             ibox_grow_pt(&ci, ctr);
@@ -782,7 +784,7 @@ static void sah_build_range(const sah_ctx* x, sah_task root, int64_t bias)
             for (int b = 0; b < 8; b++) { ibox_reset(&bp[b]); bn[b] = 0; }
             uint8_t* binof = (uint8_t*)malloc(count);
             for (uint32_t i = t.start; i < t.end; i++) {
-                const float* bx = x->aabbs[in[i] & 0x7FFFFFFFu];
+                const float* bx = x->aabbs[in[i]];
                 float ctr[3]; box_centre(bx, ctr);
                 int32_t bin = cvt_rzi(k1 * (ctr[axis] - cbox[axis]));
                 if (bin < 0) bin = 0;                         /* the reference reports an error and aborts the build */
@@ -832,60 +834,135 @@ static void sah_build_range(const sah_ctx* x, sah_task root, int64_t bias)
     free(stack);
 }
 
-uint32_t ora_build_sah(const ora_triangle* tris, uint32_t n, int enable_pairs, ora_node* nodes, ora_triangle_pair* leaves,
-                       uint32_t* cell_counts_out)
+/* fmaxf / fminf of AABB::Intersection (Common.cuh:269-272) on the ordered-int encoding */
+static inline float fmin_ord(float a, float b) { return ora_float_to_ordered_int(a) < ora_float_to_ordered_int(b) ? a : b; }
+static inline float fmax_ord(float a, float b) { return ora_float_to_ordered_int(a) > ora_float_to_ordered_int(b) ? a : b; }
+static inline void box_intersection(const float* a, const float* b, float* out)
 {
-    /* ---- Setup (Multiblock.cu:139-207): leaves, their boxes, global primitive / centroid bounds */
-    float (*aabbs)[6] = (float (*)[6])malloc(((size_t)n + SAH_CELLS) * 24);
-    uint8_t* two = (uint8_t*)malloc((size_t)n + 1);
+    for (int k = 0; k < 3; k++) { out[k] = fmax_ord(a[k], b[k]); out[3 + k] = fmin_ord(a[3 + k], b[3 + k]); }
+}
+static inline int box_valid(const float* b) { return b[3] >= b[0] && b[4] >= b[1] && b[5] >= b[2]; }   /* Common.cuh:274-277 */
+/* CalculateGridcell (Multiblock.cu:86-91) */
+static inline void grid_cell(const float* p, const float* g, int32_t* c)
+{
+    for (int k = 0; k < 3; k++) {
+        int32_t q = cvt_rzi(floorf((p[k] - g[k]) * 4.0f / (g[3 + k] - g[k])));
+        c[k] = q < 0 ? 0 : (q > 3 ? 3 : q);
+    }
+}
+/* CellToBounds (Multiblock.cu:93-102) */
+static inline void cell_bounds(const int32_t* c, const float* g, float* out)
+{
+    for (int k = 0; k < 3; k++) {
+        const float step = (g[3 + k] - g[k]) / 4.0f;
+        out[k] = g[k] + (float)c[k] * step;
+        out[3 + k] = g[k] + (float)(c[k] + 1) * step;
+    }
+}
+static void make_leaf(ora_triangle_pair* r, const ora_triangle* a, const ora_triangle* b, uint32_t ida)
+{
+    memset(r, 0, sizeof *r);
+    if (b) {                                                 /* CreateTrianglePair (Pairing.cuh:60-77) */
+        int ra = 0, rb = 0;
+        can_form_pair(a, b, &ra, &rb);
+        ora_triangle ar = *a;                                /* RotateTriangle (Pairing.cuh:9-21) */
+        if (ra == 1) { ar.v0 = a->v2; ar.v1 = a->v0; ar.v2 = a->v1; }
+        else if (ra == 2) { ar.v0 = a->v1; ar.v1 = a->v2; ar.v2 = a->v0; }
+        r->v0 = ar.v0; r->v1 = ar.v1; r->v2 = ar.v2;
+        r->v3 = rb == 2 ? b->v0 : rb == 1 ? b->v1 : b->v2;
+        r->primitive_id_0 = ida; r->primitive_id_1 = ida + 1;
+        r->rot_x = (uint16_t)ra; r->rot_y = (uint16_t)rb;
+    } else {
+        r->v0 = a->v0; r->v1 = a->v1; r->v2 = a->v2; r->v3 = a->v2;
+        r->primitive_id_0 = ida;
+    }
+}
+
+uint32_t ora_build_sah(const ora_triangle* tris, uint32_t n, int enable_pairs, int enable_splits, ora_node* nodes,
+                       ora_triangle_pair* leaves, uint32_t* cell_counts_out, uint32_t* num_leaf_records_out)
+{
+    /* ---- Setup / SetupSplits / SetupPairSplits (Multiblock.cu:139-425): leaf records, the items of the build (one per
+     * leaf, or one per (leaf, grid cell) reference with splits), their boxes, global primitive / centroid bounds.
+     * The split budget (extra_leaves, an atomic counter in the reference) is consumed in input order. */
+    const uint32_t thresh = n / 5;                               /* extra_leaves_threshold (BuildWrapper.cu:143) */
+    const uint32_t top_base = n + (enable_splits ? thresh : 0);  /* items < top_base; the cells' items start here */
+    float (*aabbs)[6] = (float (*)[6])malloc(((size_t)top_base + SAH_CELLS) * 24);
+    uint32_t* item_leaf = (uint32_t*)malloc(((size_t)top_base + 1) * 4);
     ibox gp, gc;
     ibox_reset(&gp); ibox_reset(&gc);
-    uint32_t L = 0;
-    for (uint32_t tid = 0; tid < n; tid += 2) {
-        const int second_valid = tid + 1 < n;
+    float grid[6] = {0, 0, 0, 0, 0, 0};
+    if (enable_splits) {                                         /* CalculateSceneAabb first (BuildWrapper.cu:189-192) */
+        int32_t sb[6];
+        ora_scene_aabb(tris, n, sb);
+        for (int k = 0; k < 6; k++) { gp.v[k] = sb[k]; grid[k] = ora_ordered_int_to_float(sb[k]); }
+    }
+    uint32_t L = 0, R = 0, budget = 0;                           /* items, leaf records, extra_leaves counter */
+    for (uint32_t tid = 0; tid < n; tid += (enable_pairs || !enable_splits) ? 2 : 1) {
+        /* SetupSplits walks single triangles; Setup and SetupPairSplits walk candidates (2k, 2k+1) */
+        const int by_pairs = enable_pairs || !enable_splits;
+        const int second_valid = by_pairs && tid + 1 < n;
         const ora_triangle *a = &tris[tid], *b = second_valid ? &tris[tid + 1] : &tris[tid];
-        float ab[6], bb[6], pb[6], ac[3], bc[3];
+        float ab[6], bb[6], ac[3], bc[3];
         tri_box(a, ab); tri_box(b, bb);
         box_centre(ab, ac); box_centre(bb, bc);
-        for (int k = 0; k < 3; k++) { pb[k] = fminf(ab[k], bb[k]); pb[3 + k] = fmaxf(ab[3 + k], bb[3 + k]); }
-        ibox_grow_box(&gp, ab); ibox_grow_box(&gp, bb);          /* AtomicConvertCombine(*s_p_aabb, Combine(a, b)) */
-        ibox_grow_pt(&gc, ac); ibox_grow_pt(&gc, bc);            /* c_aabb = {min(a_c, b_c), max(a_c, b_c)} */
         const int merge = enable_pairs && second_valid && pair_merges(tris, n, tid);
-        ora_triangle_pair r;
-        if (merge) {
-            memset(&r, 0, sizeof r);
-            int ra = 0, rb = 0;
-            can_form_pair(a, b, &ra, &rb);
-            ora_triangle ar = *a;                                /* RotateTriangle (Pairing.cuh:9-21) */
-            if (ra == 1) { ar.v0 = a->v2; ar.v1 = a->v0; ar.v2 = a->v1; }
-            else if (ra == 2) { ar.v0 = a->v1; ar.v1 = a->v2; ar.v2 = a->v0; }
-            r.v0 = ar.v0; r.v1 = ar.v1; r.v2 = ar.v2;
-            r.v3 = rb == 2 ? b->v0 : rb == 1 ? b->v1 : b->v2;
-            r.primitive_id_0 = tid; r.primitive_id_1 = tid + 1;
-            r.rot_x = (uint16_t)ra; r.rot_y = (uint16_t)rb;
-            leaves[L] = r;
-            /* the union on the ordered-int encoding, like every other box of this path */
-            ibox u; ibox_reset(&u); ibox_grow_box(&u, ab); ibox_grow_box(&u, bb); ibox_to_float(&u, aabbs[L]);
-            (void)pb;
-            two[L] = 1;
-            L++;
-        } else {
-            for (int s = 0; s < 1 + second_valid; s++) {
-                const ora_triangle* t = s ? b : a;
-                memset(&r, 0, sizeof r);
-                r.v0 = t->v0; r.v1 = t->v1; r.v2 = t->v2; r.v3 = t->v2;
-                r.primitive_id_0 = tid + s;
-                leaves[L] = r;
-                memcpy(aabbs[L], s ? bb : ab, 24);
-                two[L] = 0;
-                L++;
+        float ub[6];
+        { ibox u; ibox_reset(&u); ibox_grow_box(&u, ab); ibox_grow_box(&u, bb); ibox_to_float(&u, ub); }
+        if (!enable_splits) {
+            ibox_grow_box(&gp, ab); ibox_grow_box(&gp, bb);      /* AtomicConvertCombine(*s_p_aabb, Combine(a, b)) */
+            ibox_grow_pt(&gc, ac); ibox_grow_pt(&gc, bc);        /* c_aabb = {min(a_c, b_c), max(a_c, b_c)} */
+        }
+        const int nleaf = merge ? 1 : 1 + second_valid;
+        for (int s = 0; s < nleaf; s++) {
+            const float* box = merge ? ub : (s ? bb : ab);
+            make_leaf(&leaves[R], s ? b : a, merge ? b : NULL, tid + (uint32_t)s);
+            const uint32_t leafv = R | (merge ? 0x80000000u : 0u);
+            R++;
+            int split = 0;
+            int32_t lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+            if (enable_splits) {
+                grid_cell(box, grid, lo);
+                grid_cell(box + 3, grid, hi);
+                split = lo[0] != hi[0] || lo[1] != hi[1] || lo[2] != hi[2];
+                const uint32_t extra = (uint32_t)((hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1) - 1);
+                if (split) { split = budget + extra < thresh; budget += extra; }   /* atomicAdd happens either way */
             }
+            if (!split) {
+                memcpy(aabbs[L], box, 24);
+                item_leaf[L] = leafv;
+                if (enable_splits) { float c[3]; box_centre(box, c); ibox_grow_pt(&gc, c); }
+                L++;
+                continue;
+            }
+            int32_t c[3];
+            for (c[2] = lo[2]; c[2] <= hi[2]; c[2]++)            /* GridNextCell order: x fastest (Multiblock.cu:118-134) */
+                for (c[1] = lo[1]; c[1] <= hi[1]; c[1]++)
+                    for (c[0] = lo[0]; c[0] <= hi[0]; c[0]++) {
+                        float cb[6], out[6];
+                        cell_bounds(c, grid, cb);
+                        if (merge) {                             /* (:362-378) */
+                            float ia[6], ibx[6];
+                            box_intersection(ab, cb, ia);
+                            box_intersection(bb, cb, ibx);
+                            if (!box_valid(ia) && !box_valid(ibx)) continue;
+                            ibox u; ibox_reset(&u); ibox_grow_box(&u, ia); ibox_grow_box(&u, ibx); ibox_to_float(&u, out);
+                        } else {
+                            box_intersection(box, cb, out);
+                        }
+                        memcpy(aabbs[L], out, 24);
+                        item_leaf[L] = leafv;
+                        float ctr[3]; box_centre(out, ctr);
+                        ibox_grow_box(&gp, out);
+                        ibox_grow_pt(&gc, ctr);
+                        L++;
+                    }
         }
     }
+    if (num_leaf_records_out) *num_leaf_records_out = R;
     /* every slot this build can leave unwritten is defined as type None */
     memset(nodes, 0, sizeof(ora_node) * ((size_t)2 * SAH_CELLS + 2 * (size_t)L + 2));
     uint32_t cell_count[SAH_CELLS] = {0}, cell_start[SAH_CELLS];
-    if (L == 0) { free(aabbs); free(two); if (cell_counts_out) memcpy(cell_counts_out, cell_count, sizeof cell_count); return 0; }
+    if (L == 0) { free(aabbs); free(item_leaf); if (cell_counts_out) memcpy(cell_counts_out, cell_count, sizeof cell_count); return 0; }
 
     /* ---- GridBlockCounts / Scan / Distribute (:427-546) */
     float gcf[6], gpf[6];
@@ -912,19 +989,19 @@ uint32_t ora_build_sah(const ora_triangle* tris, uint32_t n, int enable_pairs, o
     uint32_t run = 0;
     for (int b = 0; b < SAH_CELLS; b++) { cell_start[b] = run; run += cell_count[b]; }
     if (cell_counts_out) memcpy(cell_counts_out, cell_count, sizeof cell_count);
-    uint32_t* ids0 = (uint32_t*)malloc(((size_t)n + SAH_CELLS) * 4);
-    uint32_t* ids1 = (uint32_t*)malloc(((size_t)n + SAH_CELLS) * 4);
+    uint32_t* ids0 = (uint32_t*)malloc(((size_t)top_base + SAH_CELLS) * 4);
+    uint32_t* ids1 = (uint32_t*)malloc(((size_t)top_base + SAH_CELLS) * 4);
     {
         uint32_t cur[SAH_CELLS];
         memcpy(cur, cell_start, sizeof cur);
-        for (uint32_t i = 0; i < L; i++) ids0[cur[cell_of[i]]++] = i | (two[i] ? 0x80000000u : 0u);
+        for (uint32_t i = 0; i < L; i++) ids0[cur[cell_of[i]]++] = i;
     }
     uint32_t K = 0;
     for (int b = 0; b < SAH_CELLS; b++) {
-        ibox_to_float(&cell_p[b], aabbs[n + b]);
-        if (cell_count[b]) ids0[n + K++] = n + (uint32_t)b;
+        ibox_to_float(&cell_p[b], aabbs[top_base + b]);
+        if (cell_count[b]) ids0[top_base + K++] = top_base + (uint32_t)b;
     }
-    sah_ctx x = {nodes, (const float (*)[6])aabbs, {ids0, ids1}, n, cell_start};
+    sah_ctx x = {nodes, (const float (*)[6])aabbs, {ids0, ids1}, top_base, cell_start, item_leaf};
     /* ---- SharedTaskBuild per cell: root descriptor at 2*64 + 2*start_b (SharedTaskBuilder.cu:116-127) */
     for (int b = 0; b < SAH_CELLS; b++) {
         if (!cell_count[b]) continue;
@@ -934,11 +1011,11 @@ uint32_t ora_build_sah(const ora_triangle* tris, uint32_t n, int enable_pairs, o
     }
     /* ---- SharedTaskBuild(top_of_tree): items = non-empty cells, c / p = the global bounds, root descriptor slot 0 */
     {
-        sah_task t = {n, n + K, 0, 0, {0}, 1};
+        sah_task t = {top_base, top_base + K, 0, 0, {0}, 1};
         memcpy(t.c, gcf, 24);
-        sah_build_range(&x, t, -2 * (int64_t)n);
+        sah_build_range(&x, t, -2 * (int64_t)top_base);
     }
-    free(aabbs); free(two); free(cell_of); free(ids0); free(ids1);
+    free(aabbs); free(item_leaf); free(cell_of); free(ids0); free(ids1);
     return L;
 }
 

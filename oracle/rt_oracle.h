@@ -140,9 +140,14 @@ uint32_t ora_build_hybrid_top(ora_node* nodes, uint32_t L, const int32_t aabb_or
 /* SAH path: RunSahBuild (BuildWrapper.cu:140-251) without spatial splits, restated
  * deterministically -- see the comment above ora_build_sah in rt_oracle.c for the numbering rules.  nodes must hold
  * 2*64 + 2*n + 2 slots (the reference allocates 4*(n+512), main.cu:235-237), leaves n entries.  Trace root =
- * (slot 0, count 1).  cell_counts_out (may be NULL): leaves per grid cell [64].  Returns the number of leaves L. */
-uint32_t ora_build_sah(const ora_triangle* tris, uint32_t n, int enable_pairs, ora_node* nodes, ora_triangle_pair* leaves,
-                       uint32_t* cell_counts_out);
+ * (slot 0, count 1).  enable_splits: SetupSplits / SetupPairSplits (Multiblock.cu:209-425) -- a leaf whose box spans
+ * several cells of the 4x4x4 grid over the SCENE box is referenced once per cell with its box clipped to the cell,
+ * while the running sum of extra references (taken in input order here; an atomic counter in the reference) stays
+ * below n/5.  nodes then needs 2*64 + 2*(n + n/5) + 2 slots.  cell_counts_out (may be NULL): items per grid cell
+ * [64]; num_leaf_records_out (may be NULL): TrianglePair records written.  Returns the number of items L (leaves,
+ * or leaf references with splits). */
+uint32_t ora_build_sah(const ora_triangle* tris, uint32_t n, int enable_pairs, int enable_splits, ora_node* nodes,
+                       ora_triangle_pair* leaves, uint32_t* cell_counts_out, uint32_t* num_leaf_records_out);
 
 /* Utilities.cpp:8-44 : out[3] = {numNodes, numLeafNodes, numTreeNodes} */
 void ora_count_nodes(const ora_node* nodes, uint32_t root, uint32_t count, int32_t out[3]);

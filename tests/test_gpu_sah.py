@@ -19,41 +19,45 @@ def _scenes(scenes):
         "two": scenes.grid_mesh(4, 1)[:2],
         "three": scenes.grid_mesh(4, 1)[:3],
         "odd": scenes.grid_mesh(9, 4)[:161],
+        "bigsoup": scenes.soup(20000, 9, size=0.6),             # large triangles: most want a split, the budget runs out
         "line": np.concatenate([scenes.grid_mesh(1, 1)[:1] + np.float32(i) * np.array([1, 0, 0] * 3, np.float32) for i in range(500)]),
     }
 
 
-def _gpu_sah(rt, tris, pairs):
+def _gpu_sah(rt, tris, pairs, splits=False):
     import torch
     tri = np.ascontiguousarray(tris, np.float32).reshape(-1, 9)
     n = tri.shape[0]
     inp = rt.BuildInput.allocate(tri, sah=True)
     inp.nodes_out.fill_(0xCD)
     inp.triangles_out.fill_(0xCD)
-    rt.RunSahBuild(inp, rt.Arguments(build_type=rt.kSAH, enable_pairs=pairs))
+    rt.RunSahBuild(inp, rt.Arguments(build_type=rt.kSAH, enable_pairs=pairs, enable_splits=splits))
     torch.cuda.synchronize()
     lay = rt.sah_scratch_layout(n)
     status = rt.to_host(inp.scratch, np.uint32, 8, lay.status)
     assert status[0] == 0, f"build reported error flags {status[0]:#x}"
-    L = int(status[1])
-    return dict(inp=inp, n=n, L=L, nodes=rt.to_host(inp.nodes_out, rt.NODE, 128 + 2 * L),
-                leaves=rt.to_host(inp.triangles_out, rt.TRIANGLE_PAIR, L),
+    L, R = int(status[1]), int(status[2])
+    return dict(inp=inp, n=n, L=L, R=R, nodes=rt.to_host(inp.nodes_out, rt.NODE, 128 + 2 * L),
+                leaves=rt.to_host(inp.triangles_out, rt.TRIANGLE_PAIR, R),
                 cells=rt.to_host(inp.scratch, np.uint32, 64, lay.cell_counts))
 
 
+@pytest.mark.parametrize("splits", [False, True])
 @pytest.mark.parametrize("pairs", [False, True])
-@pytest.mark.parametrize("name", ["grid24", "grid100", "soup65536", "flat20", "dups4096", "one", "two", "three", "odd", "line"])
-def test_sah_build_bit_exact(name, pairs, rt, scenes, ora):
+@pytest.mark.parametrize("name", ["grid24", "grid100", "soup65536", "flat20", "dups4096", "one", "two", "three", "odd", "line", "bigsoup"])
+def test_sah_build_bit_exact(name, pairs, splits, rt, scenes, ora):
     from helpers import assert_nodes_equal
     tris = _scenes(scenes)[name]
-    g = _gpu_sah(rt, tris, pairs)
-    o = ora.build_sah(tris, pairs)
-    assert g["L"] == o["L"]
+    g = _gpu_sah(rt, tris, pairs, splits)
+    o = ora.build_sah(tris, pairs, splits)
+    assert g["L"] == o["L"] and g["R"] == o["R"]
+    if splits:
+        assert g["L"] < g["n"] + g["n"] // 5 + 1
     assert (g["cells"] == o["cell_counts"]).all(), "leaves per grid cell"
     assert g["leaves"].tobytes() == o["leaves"].tobytes(), "TrianglePair[] bytes"
     assert_nodes_equal(g["nodes"], o["nodes"], name)
     L = g["L"]
-    if L > 1:
+    if L > 1:   # (numLeafNodes counts references: a split leaf appears once per cell)
         assert ora.count_nodes(g["nodes"], 0, 1) == (2 * L - 1, L, L - 1)
         assert ora.verify_hierarchy(g["nodes"], 0, 1) == 0
         if ora.ref_available():
@@ -97,7 +101,18 @@ def test_sah_large_structure(rt, scenes, ora):
     assert ids.shape[0] == L and (ids == np.arange(L)).all(), "every leaf referenced exactly once"
 
 
-def test_sah_splits_unsupported(rt, scenes):
-    inp = rt.BuildInput.allocate(scenes.grid_mesh(4, 1), sah=True)
-    with pytest.raises(rt.RtError):
-        rt.RunSahBuild(inp, rt.Arguments(build_type=rt.kSAH, enable_splits=True))
+@pytest.mark.parametrize("pairs", [False, True])
+def test_sah_splits_frames(pairs, rt, scenes, ora):
+    """--splits: leaves referenced from several cells; same nearest hits as the unsplit trees, GPU == oracle."""
+    from helpers import gpu_build, gpu_trace
+    tris = scenes.soup(20000, 9, size=0.4)
+    bu = gpu_build(tris)
+    sah = _gpu_sah(rt, tris, pairs, True)
+    assert sah["L"] > sah["R"], "some leaves are referenced more than once"
+    cam = scenes.camera_for_box([0, 0, 0], [1, 1, 1])
+    f0, _ = gpu_trace(bu, cam, 640, 360, 0)
+    f1, c1 = gpu_trace(sah, cam, 640, 360, 0, root=0, count=1)
+    assert (f0 == f1).all()
+    o = ora.build_sah(tris, pairs, True)
+    e1, oc = ora.trace(o["leaves"], o["nodes"], 0, 1, cam, 640, 360, render_type=0)
+    assert (e1 == f1).all() and int(oc[0]) == int(c1[0]) and int(oc[1]) == int(c1[1])

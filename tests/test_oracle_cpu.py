@@ -251,18 +251,22 @@ def test_pairs_oracle(ora, scenes):
             assert (i1 == i2).all(), rtype
 
 
+@pytest.mark.parametrize("splits", [False, True])
 @pytest.mark.parametrize("pairs", [False, True])
 @pytest.mark.parametrize("scene", ["grid30", "soup3000", "flat12", "coincident"])
-def test_sah_oracle_tree_is_valid_and_renders_like_the_lbvh(scene, pairs, scenes, ora):
+def test_sah_oracle_tree_is_valid_and_renders_like_the_lbvh(scene, pairs, splits, scenes, ora):
     """ora_build_sah (RunSahBuild restated): checked by the reference's compiled VerifyHierarchy / CountNodes, by every
     leaf being referenced exactly once, by the grid-cell counts adding up, and by tracing: the same triangles give the
     same nearest hits as through the LBVH (kDepth frames equal), with fewer box tests on the mesh."""
-    tris = {"grid30": scenes.grid_mesh(30, 2), "soup3000": scenes.soup(3000, 5),
+    tris = {"grid30": scenes.grid_mesh(30, 2), "soup3000": scenes.soup(3000, 5, size=0.3 if splits else 0.02),
             "flat12": scenes.flat_mesh(12, 3),
             "coincident": np.repeat(scenes.soup(6, 3, dup_fraction=0.0), 100, axis=0)}[scene]
-    s = ora.build_sah(tris, pairs)
-    L = s["L"]
+    s = ora.build_sah(tris, pairs, splits)
+    L, R = s["L"], s["R"]            # items (leaf references with splits), TrianglePair records
     assert int(s["cell_counts"].sum()) == L
+    assert (L == R) if not splits else (R <= L < tris.shape[0] + tris.shape[0] // 5 + 1)
+    if splits and scene in ("grid30", "soup3000"):
+        assert L > R, "some leaves span grid cells and are referenced once per cell"
     assert ora.count_nodes(s["nodes"], 0, 1) == (2 * L - 1, L, L - 1)
     assert ora.verify_hierarchy(s["nodes"], 0, 1) == 0
     if ora.ref_available():
@@ -272,7 +276,7 @@ def test_sah_oracle_tree_is_valid_and_renders_like_the_lbvh(scene, pairs, scenes
     ids = w28[(w28 >> 29) == 2] & 0x1FFFFFFF
     # every leaf referenced; a cell holding ONE leaf has a Tri sub-root that the top tree copies (so it appears twice,
     # the sub-root copy being unreachable) -- CountNodes above counted the reachable ones: exactly L
-    assert (np.unique(ids) == np.arange(L)).all()
+    assert (np.unique(ids) == np.arange(R)).all()
     assert ids.shape[0] - L == int((s["cell_counts"] == 1).sum())
     # the top tree lives in slots [0, 128), cell trees above; a Box slot never points below its own region
     box = (w28 >> 29) == 1
