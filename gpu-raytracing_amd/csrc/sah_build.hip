@@ -625,10 +625,8 @@ __global__ __launch_bounds__(256) void sah_bin_kernel(SahArgs a, uint32_t lvl)
     const uint32_t chunk = blockIdx.x, pos = chunk * kSahChunk + threadIdx.x;
     const uint32_t t = pos < a.M ? a.task_of[cur][pos] : kInactive;
     const uint32_t t_prev = (threadIdx.x > 0 && pos - 1 < a.M) ? a.task_of[cur][pos - 1] : kInactive;
-    for (uint32_t j = threadIdx.x; j < kSahMaxLocal * 8 * kBinWords; j += 256) {
-        const uint32_t w = j % kBinWords;
-        (&lbins[0][0][0])[j] = w == 12 ? 0 : ((w % 6) < 3 ? kEmptyLo : kEmptyHi);
-    }
+    for (uint32_t j = threadIdx.x; j < kSahMaxLocal * 8 * kBinWords; j += 256)
+        (&lbins[0][0][0])[j] = (j % kBinWords) == 12 ? 0 : kEmptyLo;   // (~kEmptyHi == kEmptyLo: "max" words are complemented)
     uint32_t nloc;
     const uint32_t local = sah_local_runs(t, t_prev, ws, &nloc);   // ends with a barrier
     if (nloc > kSahMaxLocal) {
@@ -657,14 +655,45 @@ __global__ __launch_bounds__(256) void sah_bin_kernel(SahArgs a, uint32_t lvl)
             const int bin = min(7, max(0, cvt_rzi(k1 * (ca - cmin))));   // the reference aborts the build on an out-of-range bin
             a.binof[pos] = (uint8_t)bin;
             int* lb = &lbins[local][bin][0];
+            // 12 box words per item.  Lanes that share a (task, bin) would queue on the same LDS word (about 8 cycles
+            // per lane); the "max" words are kept complemented (max x = ~min ~x on the ordered ints) so that all 12
+            // are the same instruction, and lane i walks them starting at word i mod 12: same-address queues shrink 12x
+            int val[12];
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                atomicMin(&lb[k], float_to_ordered_int(b[k]));
-                atomicMax(&lb[3 + k], float_to_ordered_int(b[3 + k]));
-                atomicMin(&lb[6 + k], float_to_ordered_int(ctr[k]));
-                atomicMax(&lb[9 + k], float_to_ordered_int(ctr[k]));
+                val[k] = float_to_ordered_int(b[k]);
+                val[3 + k] = ~float_to_ordered_int(b[3 + k]);
+                val[6 + k] = float_to_ordered_int(ctr[k]);
+                val[9 + k] = ~float_to_ordered_int(ctr[k]);
             }
-            atomicAdd(&lb[12], 1);
+            const uint32_t r = threadIdx.x % 12u;
+#pragma unroll
+            for (int k = 0; k < 12; k++) {
+                uint32_t w = r + (uint32_t)k;
+                w = w >= 12u ? w - 12u : w;
+                int v = val[0];
+#pragma unroll
+                for (int j = 1; j < 12; j++) v = w == (uint32_t)j ? val[j] : v;
+                atomicMin(&lb[w], v);
+            }
+            // the count: one atomic per (task, bin) group of the wave instead of one per lane
+            uint64_t m = __builtin_amdgcn_ballot_w64(true);
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const bool bit = (bin >> q) & 1;
+                const uint64_t bal = __builtin_amdgcn_ballot_w64(bit);
+                m &= bit ? bal : ~bal;
+            }
+            const uint32_t l0 = __builtin_amdgcn_readfirstlane(local);
+            const uint64_t same0 = __builtin_amdgcn_ballot_w64(local == l0);
+            m &= local == l0 ? same0 : ~same0;   // (a wave holds at most a few runs; lanes of other runs pair up the same way)
+            bool lead = (threadIdx.x & 63) == (uint32_t)(__ffsll((unsigned long long)m) - 1);
+            uint32_t add = (uint32_t)__popcll(m);
+            if (local != l0) {   // runs beyond the first two in a wave: fall back to per-lane counting
+                const uint32_t l1 = __builtin_amdgcn_readfirstlane(local);
+                if (__builtin_amdgcn_ballot_w64(local == l1) != __builtin_amdgcn_ballot_w64(true)) { lead = true; add = 1; }
+            }
+            if (lead) atomicAdd(&lb[12], (int)add);
         }
     }
     __syncthreads();
@@ -681,14 +710,14 @@ __global__ __launch_bounds__(256) void sah_bin_kernel(SahArgs a, uint32_t lvl)
         if (inside) {
             int* g = a.bins[cur] + ((size_t)tl * 8 + bin) * kBinWords;
 #pragma unroll
-            for (int k = 0; k < (int)kBinWords; k++) g[k] = lbins[l][bin][k];
+            for (int k = 0; k < (int)kBinWords; k++) g[k] = (k < 12 && (k % 6) >= 3) ? ~lbins[l][bin][k] : lbins[l][bin][k];
         } else if (tl != kInactive && lbins[l][bin][12] > 0) {
             int* g = a.bins[cur] + ((size_t)ltask[l] * 8 + bin) * kBinWords;
             const int* s = &lbins[l][bin][0];
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                atomicMin(&g[k], s[k]); atomicMax(&g[3 + k], s[3 + k]);
-                atomicMin(&g[6 + k], s[6 + k]); atomicMax(&g[9 + k], s[9 + k]);
+                atomicMin(&g[k], s[k]); atomicMax(&g[3 + k], ~s[3 + k]);
+                atomicMin(&g[6 + k], s[6 + k]); atomicMax(&g[9 + k], ~s[9 + k]);
             }
             atomicAdd(&g[12], s[12]);
         }
@@ -734,8 +763,20 @@ __global__ __launch_bounds__(kSplitWaves * 64) void sah_split_kernel(SahArgs a, 
     const uint32_t cur = lvl & 1, nxt = cur ^ 1;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __shared__ uint32_t pf_c0[64], pf_c1[64], pf_plane[64];
-    __shared__ uint32_t pf_n;
-    if (threadIdx.x == 0) pf_n = 0;
+    __shared__ uint32_t pf_n, init_n;
+    __shared__ uint32_t init_ids[128];
+    // the bins of this workgroup's 64 tasks are one contiguous 26 KB block: read it coalesced, keep it in LDS with an
+    // odd row stride (a thread per task reading its row straight from memory touches 64 cache lines per load)
+    constexpr uint32_t kRow = 8 * kBinWords + 1;
+    __shared__ int sbins[64 * kRow];
+    if (threadIdx.x == 0) { pf_n = 0; init_n = 0; }
+    {
+        const uint32_t first = blockIdx.x * 64;
+        const uint32_t ntk = min(64u, ntask - first);
+        const int* src = a.bins[cur] + (size_t)first * 8 * kBinWords;
+        for (uint32_t j = threadIdx.x; j < ntk * 8 * kBinWords; j += kSplitWaves * 64)
+            sbins[(j / (8 * kBinWords)) * kRow + (j % (8 * kBinWords))] = src[j];
+    }
     __syncthreads();
     if (wave == 0) {
     const uint32_t w = blockIdx.x * 64 + lane;
@@ -752,7 +793,7 @@ __global__ __launch_bounds__(kSplitWaves * 64) void sah_split_kernel(SahArgs a, 
         for (int k = 0; k < 12; k++) cb[s][k] = (k % 6) < 3 ? kEmptyLo : kEmptyHi;
     uint32_t mid = 0, kind = 2, plane = 0;
     if (valid && !(sah_sa(T.c) <= 0.0f)) {
-        const int* g = a.bins[cur] + (size_t)w * 8 * kBinWords;
+        const int* g = &sbins[lane * kRow];
         // prefix left -> right: surface area and count of bins [0, i]
         float sa_l[7];
         uint32_t ln[7];
@@ -826,22 +867,38 @@ __global__ __launch_bounds__(kSplitWaves * 64) void sah_split_kernel(SahArgs a, 
     }
     const uint32_t child_index = (uint32_t)(bias + 2 * (int)mid);
     uint32_t cid[2] = {kInactive, kInactive};
+    {
+        // ids of the children: big ones join the next level, small ones the small-task list.  One atomic per counter and
+        // wave (issued back to back), ranks from ballots.
+        const bool bigL = valid && (mid - T.start) > kSahSmall, bigR = valid && (T.end - mid) > kSahSmall;
+        const uint64_t mbl = __builtin_amdgcn_ballot_w64(bigL), mbr = __builtin_amdgcn_ballot_w64(bigR);
+        const uint64_t msl = __builtin_amdgcn_ballot_w64(valid && !bigL), msr = __builtin_amdgcn_ballot_w64(valid && !bigR);
+        uint32_t base_big = 0, base_small = 0;
+        if (lane == 0) {
+            const uint32_t nb = (uint32_t)(__popcll(mbl) + __popcll(mbr)), ns = (uint32_t)(__popcll(msl) + __popcll(msr));
+            if (nb) base_big = atomicAdd(&a.H->level_count[lvl + 1], nb);
+            if (ns) base_small = atomicAdd(&a.H->small_count, ns);
+        }
+        base_big = __shfl(base_big, 0, 64);
+        base_small = __shfl(base_small, 0, 64);
+        const uint64_t lt = (1ull << lane) - 1ull;
+        const uint32_t idb[2] = {base_big + (uint32_t)__popcll(mbl & lt), base_big + (uint32_t)__popcll(mbl) + (uint32_t)__popcll(mbr & lt)};
+        const uint32_t ids[2] = {base_small + (uint32_t)__popcll(msl & lt), base_small + (uint32_t)__popcll(msl) + (uint32_t)__popcll(msr & lt)};
 #pragma unroll
-    for (int s = 0; s < 2; s++) {
-        const uint32_t cs = s ? mid : T.start, ce = s ? T.end : mid;
-        const bool big = valid && (ce - cs) > kSahSmall;
-        const uint32_t id = wave_alloc(&a.H->level_count[lvl + 1], big, lane);
-        const uint32_t sidx = wave_alloc(&a.H->small_count, valid && !big, lane);
-        if (big) {
-            SahTask C;
+        for (int s = 0; s < 2; s++) {
+            const uint32_t cs = s ? mid : T.start, ce = s ? T.end : mid;
+            const bool big = s ? bigR : bigL;
+            if (big) {
+                SahTask C;
 #pragma unroll
-            for (int k = 0; k < 6; k++) { C.p[k] = ordered_int_to_float(cb[s][k]); C.c[k] = ordered_int_to_float(cb[s][6 + k]); }
-            C.start = cs; C.end = ce; C.parent_idx = child_index + s; C.flags = T.flags;
-            a.tasks[nxt][id] = C;
-            sah_init_bins(a.bins[nxt], id, 0, 1);
-            cid[s] = id;
-        } else if (valid) {
-            a.small[sidx] = SahSmall{cs, ce, child_index + (uint32_t)s, (T.flags & 1u) | (nxt << 1)};
+                for (int k = 0; k < 6; k++) { C.p[k] = ordered_int_to_float(cb[s][k]); C.c[k] = ordered_int_to_float(cb[s][6 + k]); }
+                C.start = cs; C.end = ce; C.parent_idx = child_index + s; C.flags = T.flags;
+                a.tasks[nxt][idb[s]] = C;
+                cid[s] = idb[s];
+                init_ids[atomicAdd(&init_n, 1u)] = idb[s];     // its bins are reset by the whole workgroup below
+            } else if (valid) {
+                a.small[ids[s]] = SahSmall{cs, ce, child_index + (uint32_t)s, (T.flags & 1u) | (nxt << 1)};
+            }
         }
     }
     if (valid) {
@@ -859,9 +916,17 @@ __global__ __launch_bounds__(kSplitWaves * 64) void sah_split_kernel(SahArgs a, 
     }
     }   // wave 0
     __syncthreads();
-    // "goes left" prefix per chunk (stable partition across workgroups): one wave per queued task
+    // empty bins for the children that join the next level
+    for (uint32_t j = threadIdx.x; j < init_n * 8 * kBinWords; j += kSplitWaves * 64) {
+        const uint32_t wd = j % kBinWords;
+        a.bins[nxt][(size_t)init_ids[j / (8 * kBinWords)] * 8 * kBinWords + (j % (8 * kBinWords))] = wd == 12 ? 0 : ((wd % 6) < 3 ? kEmptyLo : kEmptyHi);
+    }
+    // "goes left" prefix per chunk (stable partition across workgroups).  Long tasks: one wave per task, a wave scan over
+    // its chunks.  Short ones (<= 16 chunks, the bulk at the deeper levels): one thread per (task, chunk) entry, each
+    // summing the few chunks before it -- no serial chain of dependent loads per task.
     for (uint32_t q = wave; q < pf_n; q += kSplitWaves) {
         const uint32_t k0 = pf_c0[q], k1 = pf_c1[q], pl = pf_plane[q];
+        if (k1 - k0 <= 16) continue;
         uint32_t running = 0;
         for (uint32_t base = k0; base <= k1; base += 64) {
             const uint32_t c = base + lane;
@@ -874,6 +939,17 @@ __global__ __launch_bounds__(kSplitWaves * 64) void sah_split_kernel(SahArgs a, 
             if (c <= k1 && c > k0) a.chunk_prefix[c] = running + incl - v;
             running += __shfl(incl, 63, 64);
         }
+    }
+    for (uint32_t j = threadIdx.x; j < pf_n * 16; j += kSplitWaves * 64) {
+        const uint32_t q = j >> 4, e = (j & 15) + 1;          // entry e: chunk k0 + e
+        const uint32_t k0 = pf_c0[q], k1 = pf_c1[q], pl = pf_plane[q];
+        if (k1 - k0 > 16 || k0 + e > k1) continue;
+        uint32_t sum = 0;
+        for (uint32_t c = k0; c < k0 + e; c++) {
+            const uint32_t* h = a.chunk_hist + (size_t)c * 16 + (c == k0 ? 8 : 0);
+            for (uint32_t b = 0; b <= pl; b++) sum += h[b];
+        }
+        a.chunk_prefix[k0 + e] = sum;
     }
 }
 
