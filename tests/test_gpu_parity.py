@@ -162,11 +162,28 @@ def test_trace_row_bands_and_spp(built, scenes, ora):
         assert (gi == oi).all() and (gc == oc[:2]).all()
 
 
-def test_unsupported_options_fail_loudly(rt, scenes):
+def test_bottom_up_ignores_splits_like_the_reference(rt, scenes):
+    """--splits only exists in RunSahBuild's front end (BuildWrapper.cu:188-210); RunBottomUpBuild never looks at it."""
+    import torch
+    tris = scenes.grid_mesh(12, 1)
+    a, b = rt.BuildInput.allocate(tris), rt.BuildInput.allocate(tris)
+    rt.RunBottomUpBuild(a, rt.Arguments(build_type=rt.kBottomUp))
+    rt.RunBottomUpBuild(b, rt.Arguments(build_type=rt.kBottomUp, enable_splits=True))
+    torch.cuda.synchronize()
+    k = 2 * (tris.shape[0] - 1) * 32
+    assert torch.equal(a.nodes_out[:k], b.nodes_out[:k])
+
+
+def test_invalid_arguments_fail_loudly(rt, scenes):
+    import ctypes
     tris = scenes.grid_mesh(4, 1)
     inp = rt.BuildInput.allocate(tris)
-    with pytest.raises(rt.RtError):
-        rt.RunBottomUpBuild(inp, rt.Arguments(build_type=rt.kBottomUp, enable_splits=True))
+    ci = rt._BuildInput(0, 0, tris.shape[0], 0, 0)          # null buffers
+    assert rt.lib().rt_run_bottom_up_build(ctypes.byref(ci), None, 0, None) == -1
+    assert rt.lib().rt_run_sah_build(ctypes.byref(ci), None, None) == -1
+    big = rt._BuildInput(rt._ptr(inp.triangles_in), rt._ptr(inp.triangles_out), (1 << 28) + 1, rt._ptr(inp.nodes_out),
+                         rt._ptr(inp.scratch))
+    assert rt.lib().rt_run_bottom_up_build(ctypes.byref(big), None, 0, None) == -3   # RT_ERR_TOO_LARGE, nothing launched
 
 
 def test_full_size_1m_properties(rt, scenes, ora):
