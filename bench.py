@@ -225,6 +225,44 @@ def main():
             ts.append(e0.elapsed_time(e1))
         extras["sah_build_ms"] = round(statistics.median(ts), 4)
         del sinp
+    if not args.no_extras and not sah and world == 1:
+        # (1) rebuild + trace per frame as one HIP graph (nothing in that path synchronises or allocates);
+        # (2) an on-box stream ceiling (device-to-device copy, read + write bytes) beside the 8 TB/s spec figure
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                build()
+                rt.Trace(inp.triangles_out, inp.nodes_out, frame, (W, H), cam_dev[cam], ROOT_IDX, ROOT_CNT, rows=(y0, y1), spp=args.spp)
+                side.synchronize()
+                with torch.cuda.graph(gr, stream=side):
+                    build()
+                    rt.Trace(inp.triangles_out, inp.nodes_out, frame, (W, H), cam_dev[cam], ROOT_IDX, ROOT_CNT, rows=(y0, y1), spp=args.spp)
+            torch.cuda.current_stream().wait_stream(side)
+            gr.replay()
+            torch.cuda.synchronize()
+            e0, e1 = ev(), ev()
+            e0.record()
+            for _ in range(10):
+                gr.replay()
+            e1.record()
+            e1.synchronize()
+            extras["graph_rebuild_plus_trace_ms"] = round(e0.elapsed_time(e1) / 10, 4)
+        except Exception as ex:  # noqa: BLE001  (an extra, never the headline)
+            extras["graph_rebuild_plus_trace_ms"] = f"unavailable: {type(ex).__name__}"
+        src = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        torch.cuda.synchronize()
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        e1.record()
+        e1.synchronize()
+        extras["stream_copy_gbps"] = round(2 * 5 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        del src, dst
     if args.other_camera:
         other = "b" if cam == "a" else "a"
         obox, otri, _, _ = test_counts(other)
@@ -291,7 +329,18 @@ def cpu_baseline(tris, cam, W, H, spp, render_type, G, tree="bottom-up"):
     t0 = time.perf_counter()
     ora.trace(o["leaves"], o["nodes"], o.get("root", 0), o.get("count", 2), cam, W, H, render_type=render_type, spp=spp)
     t_trace = time.perf_counter() - t0
+    # the same port on ONE thread, on a bounded sample of the frame (every 16th row band of 8 rows)
+    ora.set_threads(1)
+    rows1 = 0
+    t0 = time.perf_counter()
+    for yb in range(0, H - 7, 128):
+        ora.trace(o["leaves"], o["nodes"], o.get("root", 0), o.get("count", 2), cam, W, H, render_type=render_type, spp=spp,
+                  rows=(yb, yb + 8))
+        rows1 += 8
+    t_one = time.perf_counter() - t0
+    ora.set_threads(cores)
     return {"value": round(W * H * spp / t_trace / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "one_thread_mrays": round(W * rows1 * spp / t_one / 1e6, 3),
             "sample": f"1 full {W}x{H} frame ({spp} spp) of the same scene and camera, oracle/liboracle.so "
                       f"(-O2 -ffp-contract=off, OpenMP over rows); {'LBVH' if tree == 'bottom-up' else 'SAH'} build (single thread) of the same {tris.shape[0]} triangles",
             "build_ms": round(t_build * 1e3, 1), "trace_s": round(t_trace, 3)}
