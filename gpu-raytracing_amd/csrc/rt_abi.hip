@@ -212,6 +212,7 @@ const char* rt_error_string(int code)
 const char* rt_version_string(void)
 {
     return "rt_amd gfx950 | sort: LSD 4x8bit, tile 4096 | lbvh: LDS agglomerative, 1024 leaves/wg, fan 16, hybrid SAH top | "
+           "sah: 4x4x4 grid + level-synchronous binned SAH, wave-per-task below 64 items, pairs, splits | "
            "trace: wave64 8x8 tiles, two-phase schedule, LDS stack 16";
 }
 
