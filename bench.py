@@ -295,6 +295,10 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(kern_ms, 4),
                          "formula": "32*sum(box_tests) + 64*sum(tri_tests) + 4*W*rows",
+                         # the same bytes against the path that does bound the kernel: per-CU vector L1, 64 B/clk/CU
+                         "l1_path": {"achieved": round(achieved, 1), "peak": round(256 * 64 * 2.4, 1), "unit": "GB/s",
+                                     "frac": round(achieved / (256 * 64 * 2.4), 4),
+                                     "peak_formula": "256 CUs x 64 B/clk x 2.4 GHz"},
                          "note": "frac > 1: the 128 MB BVH is cache resident (HBM traffic = `traffic`); the measured "
                                  "limiter is the per-CU L1 path: TA busy 75 %, TCP active 87 % (profiles/r01_trace_l1_pmc.txt)"},
         }

@@ -116,3 +116,21 @@ def test_sah_splits_frames(pairs, rt, scenes, ora):
     o = ora.build_sah(tris, pairs, True)
     e1, oc = ora.trace(o["leaves"], o["nodes"], 0, 1, cam, 640, 360, render_type=0)
     assert (e1 == f1).all() and int(oc[0]) == int(c1[0]) and int(oc[1]) == int(c1[1])
+
+
+@pytest.mark.parametrize("count", [1, 2, 3, 5])
+def test_sah_tiny_trees_trace(count, rt, scenes, ora):
+    """1..5 triangles: the top tree degenerates (a Tri leaf copied into slot 0 for one triangle); frames == oracle == LBVH."""
+    from helpers import gpu_build, gpu_trace
+    tris = scenes.grid_mesh(3, 2)[:count]
+    sah = _gpu_sah(rt, tris, False)
+    lo, hi = tris.reshape(-1, 3).min(axis=0), tris.reshape(-1, 3).max(axis=0)
+    cam = scenes.make_camera(((lo[0] + hi[0]) / 2, hi[1] + 3.0, (lo[2] + hi[2]) / 2), 0.0, 1.5, 20.0)
+    f1, c1 = gpu_trace(sah, cam, 128, 96, 0, root=0, count=1)
+    o = ora.build_sah(tris)
+    e1, oc = ora.trace(o["leaves"], o["nodes"], 0, 1, cam, 128, 96, render_type=0)
+    assert (f1 == e1).all() and int(oc[0]) == int(c1[0]) and int(oc[1]) == int(c1[1])
+    assert (f1[..., 0] > 0).any(), "the triangles are visible"
+    bu = gpu_build(tris)
+    f0, _ = gpu_trace(bu, cam, 128, 96, 0)
+    assert (f0 == f1).all()
