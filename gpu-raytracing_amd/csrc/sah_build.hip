@@ -36,6 +36,7 @@ constexpr uint32_t kSahSmall = 64;        // tasks with <= 64 items are finished
 constexpr uint32_t kSahMaxLocal = 32;     // runs of equal task id a chunk can hold (tasks in the loop have >= 65 items)
 constexpr uint32_t kInactive = 0xFFFFFFFFu;
 constexpr uint32_t kSahMaxLevels = 1024;
+constexpr uint32_t kBoundParts = 64, kCellParts = 16;
 constexpr int kEmptyLo = 0x7f7fffff, kEmptyHi = (int)0x80800000;   // ordered-int FLT_MAX / -FLT_MAX (BuildWrapper.cu:170-171)
 constexpr uint32_t kBinWords = 13;        // p box [6], c box [6], count
 constexpr uint32_t kLeafMask = 0x7FFFFFFFu; // item_leaf: TrianglePair index | (two triangles ? 1 << 31 : 0)
@@ -53,6 +54,11 @@ struct SahHeader {
     uint32_t cell_count[kSahCells], cell_start[kSahCells], cell_task[kSahCells];
     int cell_p[kSahCells][6], cell_c[kSahCells][6];
     uint32_t level_count[kSahMaxLevels];
+    // same-address device atomics from different workgroups queue at about 50 ns each (they are resolved behind the
+    // eight L2s), so the bounds are reduced into several partial copies chosen by workgroup index and folded by the
+    // next kernel: chains of 16 instead of 1024
+    int part_bounds[kBoundParts][12];              // [gp 6, gc 6]
+    int part_cell[kCellParts][kSahCells][12];      // [cell_p 6, cell_c 6]
 };
 
 struct SahArgs {
@@ -137,6 +143,8 @@ __global__ void sah_init_kernel(SahHeader* H, rt_node* nodes, uint32_t n)
         for (int k = 0; k < 6; k++) { H->cell_p[t][k] = k < 3 ? kEmptyLo : kEmptyHi; H->cell_c[t][k] = k < 3 ? kEmptyLo : kEmptyHi; }
     }
     for (uint32_t i = t; i < kSahMaxLevels; i += blockDim.x) H->level_count[i] = 0;
+    for (uint32_t i = t; i < kBoundParts * 12; i += blockDim.x) (&H->part_bounds[0][0])[i] = (i % 6) < 3 ? kEmptyLo : kEmptyHi;
+    for (uint32_t i = t; i < kCellParts * kSahCells * 12; i += blockDim.x) (&H->part_cell[0][0][0])[i] = (i % 6) < 3 ? kEmptyLo : kEmptyHi;
     // the top tree's slots [0, 128): whatever the build does not write is type None
     for (uint32_t i = t; i < 2 * kSahCells * 2; i += blockDim.x) reinterpret_cast<uint4*>(nodes)[i] = make_uint4(0, 0, 0, 0);
 }
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(256) void sah_setup_kernel(const float* __restrict_
     }   // tiles
     __syncthreads();
     if (threadIdx.x < 12) {
-        int* g = threadIdx.x < 6 ? &H->gp[threadIdx.x] : &H->gc[threadIdx.x - 6];
+        int* g = &H->part_bounds[blockIdx.x % kBoundParts][threadIdx.x];
         if ((threadIdx.x % 6) < 3) atomicMin(g, sb[threadIdx.x]); else atomicMax(g, sb[threadIdx.x]);
     }
 }
@@ -451,15 +459,31 @@ __global__ __launch_bounds__(256) void sah_split_pass_kernel(SplitPassArgs a)
             if ((threadIdx.x & 63) == 0) { atomicMin(&sb[j], l); atomicMax(&sb[3 + j], h); }
         }
         __syncthreads();
-        if (threadIdx.x < 6) { if (threadIdx.x < 3) atomicMin(&a.H->gc[threadIdx.x], sb[threadIdx.x]); else atomicMax(&a.H->gc[threadIdx.x], sb[threadIdx.x]); }
+        if (threadIdx.x < 6) {
+            int* g = &a.H->part_bounds[blockIdx.x % kBoundParts][6 + threadIdx.x];
+            if (threadIdx.x < 3) atomicMin(g, sb[threadIdx.x]); else atomicMax(g, sb[threadIdx.x]);
+        }
     }
 }
 
 // GridBlockCounts (Multiblock.cu:427-468): the grid cell of every leaf (the key of the distribution pass) and the
 // per-cell primitive / centroid bounds.  The cell counts come out of the radix pass (its digit totals).
 __global__ __launch_bounds__(256) void sah_grid_kernel(const float* __restrict__ aabbs, uint32_t n, const uint32_t* n_dev,
-                                                       SahHeader* H, uint32_t* __restrict__ keys)
+                                                       SahHeader* H, uint32_t* __restrict__ keys, int publish_gp)
 {
+    // fold the partial scene bounds of the previous kernel (every workgroup does; workgroup 0 publishes them)
+    __shared__ int fold[12];
+    if (threadIdx.x < 12) fold[threadIdx.x] = (threadIdx.x % 6) < 3 ? kEmptyLo : kEmptyHi;
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < kBoundParts * 12; j += 256) {
+        const int v = (&H->part_bounds[0][0])[j];
+        if ((j % 6) < 3) atomicMin(&fold[j % 12], v); else atomicMax(&fold[j % 12], v);
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x < 12) {
+        if (threadIdx.x >= 6) H->gc[threadIdx.x - 6] = fold[threadIdx.x];
+        else if (publish_gp) H->gp[threadIdx.x] = fold[threadIdx.x];
+    }
     const uint32_t L = n_dev ? *n_dev : n;
     __shared__ int cp[kSahCells][6], cc[kSahCells][6];
     __shared__ uint32_t cnt[kSahCells];
@@ -471,7 +495,7 @@ __global__ __launch_bounds__(256) void sah_grid_kernel(const float* __restrict__
     __syncthreads();
     float glo[3], ghi[3];
 #pragma unroll
-    for (int k = 0; k < 3; k++) { glo[k] = ordered_int_to_float(H->gc[k]); ghi[k] = ordered_int_to_float(H->gc[3 + k]); }
+    for (int k = 0; k < 3; k++) { glo[k] = ordered_int_to_float(fold[6 + k]); ghi[k] = ordered_int_to_float(fold[9 + k]); }
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < ((L + 255) & ~255u); i += gridDim.x * 256) {
     int cell = -1;
     int v[12];
@@ -525,8 +549,9 @@ __global__ __launch_bounds__(256) void sah_grid_kernel(const float* __restrict__
         const uint32_t c = threadIdx.x;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            atomicMin(&H->cell_p[c][k], cp[c][k]); atomicMax(&H->cell_p[c][3 + k], cp[c][3 + k]);
-            atomicMin(&H->cell_c[c][k], cc[c][k]); atomicMax(&H->cell_c[c][3 + k], cc[c][3 + k]);
+            int* g = &H->part_cell[blockIdx.x % kCellParts][c][0];
+            atomicMin(&g[k], cp[c][k]); atomicMax(&g[3 + k], cp[c][3 + k]);
+            atomicMin(&g[6 + k], cc[c][k]); atomicMax(&g[9 + k], cc[c][3 + k]);
         }
     }
 }
@@ -551,6 +576,12 @@ __global__ __launch_bounds__(128) void sah_roots_kernel(SahArgs a, const uint32_
     const uint32_t start = block_excl_scan_u32<128>(cnt, ws, &total);
     const uint32_t k = block_excl_scan_u32<128>(cnt ? 1u : 0u, ws, &K);
     if (t < kSahCells) {
+        for (uint32_t q = 0; q < kCellParts; q++)
+            for (int j = 0; j < 6; j++) {
+                const int pv = H->part_cell[q][t][j], cv = H->part_cell[q][t][6 + j];
+                if (j < 3) { H->cell_p[t][j] = min(H->cell_p[t][j], pv); H->cell_c[t][j] = min(H->cell_c[t][j], cv); }
+                else { H->cell_p[t][j] = max(H->cell_p[t][j], pv); H->cell_c[t][j] = max(H->cell_c[t][j], cv); }
+            }
         H->cell_count[t] = cnt;
         H->cell_start[t] = start;
         float pb[6], cb[6];
@@ -1272,7 +1303,7 @@ hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, boo
     sah_init_kernel<<<1, 256, 0, st>>>(a.H, nodes, n);
     if (n == 0) return hipGetLastError();
     const uint32_t cand = (n + 1) / 2, cblocks = (cand + 255) / 256;
-    const uint32_t pblocks = cblocks < 256 ? cblocks : 256;
+    const uint32_t pblocks = cblocks < 1024 ? cblocks : 1024;
     uint8_t* pflags = nullptr;
     uint32_t* psums = nullptr;
     hipError_t e = hipSuccess;
@@ -1305,7 +1336,7 @@ hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, boo
         sah_setup_kernel<<<pblocks, 256, 0, st>>>(reinterpret_cast<const float*>(tris), n, leaves, aabbs, a.ids[1], item_leaf, a.H, pflags, psums);
     }
     const uint32_t iblocks = (a.B + 255) / 256;
-    sah_grid_kernel<<<iblocks < 256 ? iblocks : 256, 256, 0, st>>>(aabbs, a.B, n_dev, a.H, a.task_of[1]);
+    sah_grid_kernel<<<iblocks < 1024 ? iblocks : 1024, 256, 0, st>>>(aabbs, a.B, n_dev, a.H, a.task_of[1], splits ? 0 : 1);
     // GridBlockDistribute: cell members in ascending leaf index = one stable radix pass on the cell id
     uint32_t* digit_total = nullptr;
     e = launch_radix_pass(a.task_of[1], a.ids[1], a.task_of[0], a.ids[0], a.B, 0, s + L.sort, st, n_dev, &digit_total);
