@@ -560,7 +560,7 @@ __device__ __forceinline__ void sah_init_bins(int* bins, uint32_t task, uint32_t
 {
     for (uint32_t j = lane; j < 8 * kBinWords; j += stride) {
         const uint32_t w = j % kBinWords;
-        bins[(size_t)task * 8 * kBinWords + j] = w == 12 ? 0 : ((w % 6) < 3 ? kEmptyLo : kEmptyHi);
+        bins[(size_t)task * 8 * kBinWords + j] = w == 12 ? 0 : kEmptyLo;   // max words are kept complemented (~kEmptyHi)
     }
 }
 
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(256) void sah_bin_kernel(SahArgs a, uint32_t lvl)
     if (a.H->level_count[lvl] == 0) return;
     const uint32_t cur = lvl & 1;
     __shared__ int lbins[kSahMaxLocal][8][kBinWords];
-    __shared__ uint32_t ltask[kSahMaxLocal];
+    __shared__ uint32_t ltask[kSahMaxLocal], lstate[kSahMaxLocal];
     __shared__ uint32_t ws[8];
     const uint32_t chunk = blockIdx.x, pos = chunk * kSahChunk + threadIdx.x;
     const uint32_t t = pos < a.M ? a.task_of[cur][pos] : kInactive;
@@ -728,29 +728,33 @@ __global__ __launch_bounds__(256) void sah_bin_kernel(SahArgs a, uint32_t lvl)
         }
     }
     __syncthreads();
-    {
-        const uint32_t l = threadIdx.x >> 3, bin = threadIdx.x & 7;
-        // a task that lies inside this chunk (not the first run continuing from the left, not the last run
-        // continuing to the right) owns its bins: plain stores, no atomics
-        const uint32_t tl = l < nloc ? ltask[l] : kInactive;
-        bool inside = false;
+    // ---- flush.  Global bins keep the LDS form (max words complemented).  A task that lies inside this chunk owns its
+    // bins: plain stores.  A run continuing from the left or to the right shares them with other chunks: atomics --
+    // one LANE per word, so a run costs two atomic wave-instructions instead of 13 per wave (a CU issues about one
+    // atomic wave-instruction per 50 ns).
+    if (threadIdx.x < nloc) {
+        const uint32_t tl = ltask[threadIdx.x];
+        uint32_t st = 2;   // inactive
         if (tl != kInactive) {
             const SahTask* T = &a.tasks[cur][tl];
-            inside = T->start >= chunk * kSahChunk && T->end <= (chunk + 1) * kSahChunk;
+            st = (T->start >= chunk * kSahChunk && T->end <= (chunk + 1) * kSahChunk) ? 1u : 0u;
         }
-        if (inside) {
-            int* g = a.bins[cur] + ((size_t)tl * 8 + bin) * kBinWords;
-#pragma unroll
-            for (int k = 0; k < (int)kBinWords; k++) g[k] = (k < 12 && (k % 6) >= 3) ? ~lbins[l][bin][k] : lbins[l][bin][k];
-        } else if (tl != kInactive && lbins[l][bin][12] > 0) {
-            int* g = a.bins[cur] + ((size_t)ltask[l] * 8 + bin) * kBinWords;
-            const int* s = &lbins[l][bin][0];
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                atomicMin(&g[k], s[k]); atomicMax(&g[3 + k], ~s[3 + k]);
-                atomicMin(&g[6 + k], s[6 + k]); atomicMax(&g[9 + k], ~s[9 + k]);
+        lstate[threadIdx.x] = st;
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < nloc * 8 * kBinWords; j += 256) {
+        const uint32_t l = j / (8 * kBinWords), w = j % (8 * kBinWords);
+        if (lstate[l] == 1) a.bins[cur][(size_t)ltask[l] * 8 * kBinWords + w] = (&lbins[l][0][0])[w];
+    }
+    {
+        const uint32_t which = threadIdx.x >> 7, j = threadIdx.x & 127;
+        const uint32_t l = which ? nloc - 1 : 0;
+        if (!(which && nloc == 1) && j < 8 * kBinWords && lstate[l] == 0) {
+            const uint32_t bin = j / kBinWords, w = j % kBinWords;
+            if (lbins[l][bin][12] > 0) {
+                int* g = a.bins[cur] + (size_t)ltask[l] * 8 * kBinWords + j;
+                if (w == 12) atomicAdd(g, lbins[l][bin][12]); else atomicMin(g, lbins[l][bin][w]);
             }
-            atomicAdd(&g[12], s[12]);
         }
     }
     // the bin histogram of the first and of the last run: what a task spanning several chunks needs for its partition
@@ -790,7 +794,10 @@ constexpr uint32_t kSplitWaves = 8;
 __global__ __launch_bounds__(kSplitWaves * 64) void sah_split_kernel(SahArgs a, uint32_t lvl)
 {
     const uint32_t ntask = a.H->level_count[lvl];
-    if (blockIdx.x * 64 >= ntask) return;
+    // tasks per workgroup: 64 when the level is wide; 8 while it is narrow (the first levels, where every task spans
+    // many chunks and the per-task wave work below would otherwise queue 8 deep in ONE workgroup)
+    const uint32_t tpb = ntask > 2048 ? 64u : 8u;
+    if (blockIdx.x * tpb >= ntask) return;
     const uint32_t cur = lvl & 1, nxt = cur ^ 1;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __shared__ uint32_t pf_c0[64], pf_c1[64], pf_plane[64];
@@ -802,16 +809,20 @@ __global__ __launch_bounds__(kSplitWaves * 64) void sah_split_kernel(SahArgs a, 
     __shared__ int sbins[64 * kRow];
     if (threadIdx.x == 0) { pf_n = 0; init_n = 0; }
     {
-        const uint32_t first = blockIdx.x * 64;
-        const uint32_t ntk = min(64u, ntask - first);
+        const uint32_t first = blockIdx.x * tpb;
+        const uint32_t ntk = min(tpb, ntask - first);
         const int* src = a.bins[cur] + (size_t)first * 8 * kBinWords;
         for (uint32_t j = threadIdx.x; j < ntk * 8 * kBinWords; j += kSplitWaves * 64)
-            sbins[(j / (8 * kBinWords)) * kRow + (j % (8 * kBinWords))] = src[j];
+        {
+            const uint32_t wd = (j % (8 * kBinWords)) % kBinWords;
+            const int v = src[j];
+            sbins[(j / (8 * kBinWords)) * kRow + (j % (8 * kBinWords))] = (wd < 12 && (wd % 6) >= 3) ? ~v : v;   // max words are stored complemented
+        }
     }
     __syncthreads();
     if (wave == 0) {
-    const uint32_t w = blockIdx.x * 64 + lane;
-    const bool valid = w < ntask;
+    const uint32_t w = blockIdx.x * tpb + lane;
+    const bool valid = lane < tpb && w < ntask;
     SahTask T = {};
     if (valid) T = a.tasks[cur][w];
     const uint32_t count = T.end - T.start;
@@ -950,7 +961,7 @@ __global__ __launch_bounds__(kSplitWaves * 64) void sah_split_kernel(SahArgs a, 
     // empty bins for the children that join the next level
     for (uint32_t j = threadIdx.x; j < init_n * 8 * kBinWords; j += kSplitWaves * 64) {
         const uint32_t wd = j % kBinWords;
-        a.bins[nxt][(size_t)init_ids[j / (8 * kBinWords)] * 8 * kBinWords + (j % (8 * kBinWords))] = wd == 12 ? 0 : ((wd % 6) < 3 ? kEmptyLo : kEmptyHi);
+        a.bins[nxt][(size_t)init_ids[j / (8 * kBinWords)] * 8 * kBinWords + (j % (8 * kBinWords))] = wd == 12 ? 0 : kEmptyLo;
     }
     // "goes left" prefix per chunk (stable partition across workgroups).  Long tasks: one wave per task, a wave scan over
     // its chunks.  Short ones (<= 16 chunks, the bulk at the deeper levels): one thread per (task, chunk) entry, each
@@ -1346,7 +1357,7 @@ hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, boo
 
     const uint32_t chunks = (a.M + kSahChunk - 1) / kSahChunk;
     const uint32_t TA = a.M / (kSahSmall + 1) + 2;
-    const uint32_t split_blocks = (TA + 63) / 64;
+    const uint32_t split_blocks = (TA + 63) / 64 > 2048 / 8 ? (TA + 63) / 64 : (TA < 2048 ? (TA + 7) / 8 : 2048 / 8);
     uint32_t lvl = 0;
     // levels until every task has <= kSahSmall items: about log2(items per cell / kSahSmall) when the splits are
     // balanced; the first batch adds a margin, later batches are short
