@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--camera", choices=["a", "b"], default="a")
     ap.add_argument("--render-type", type=int, default=0)
     ap.add_argument("--build-reps", type=int, default=10)
-    ap.add_argument("--type", choices=["bottom-up", "sah", "sah-pairs"], default="bottom-up",
+    ap.add_argument("--type", choices=["bottom-up", "hybrid", "sah", "sah-pairs"], default="bottom-up",
                     help="tree the rays are traced through: the LBVH of the headline metric (default) or the SAH tree "
                          "(rt_run_sah_build, the reference's default --type; reported as a separate workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -90,16 +90,17 @@ def main():
     G, W, H = args.grid, args.width, args.height
     tris = scenes.grid_mesh(G, 1)
     n = tris.shape[0]
-    sah = args.type != "bottom-up"
+    sah = args.type in ("sah", "sah-pairs")
+    hybrid = args.type == "hybrid"
     inp = rt.BuildInput.allocate(tris, sah=sah)
     sah_args = rt.Arguments(build_type=rt.kSAH, enable_pairs=args.type == "sah-pairs")
-    ROOT_IDX, ROOT_CNT = (0, 1) if sah else (0, 2)      # main.cu:222-223
+    ROOT_IDX, ROOT_CNT = (0, 1) if sah else ((2 * n + 1, 2) if hybrid else (0, 2))      # main.cu:222-223
 
     def build():
         if sah:
             rt.RunSahBuild(inp, sah_args)
         else:
-            rt.RunBottomUpBuild(inp)
+            rt.RunBottomUpBuild(inp, hybrid=hybrid)
 
     def ev():
         return torch.cuda.Event(enable_timing=True)
@@ -209,7 +210,7 @@ def main():
             "build_ms": round(build_ms, 4),
             "build_gbps_algorithmic": round(512.0 * n / (build_ms * 1e-3) / 1e9, 1),  # 512 B/triangle, SURVEY 8(d)
         }
-    if not args.no_extras and not sah and world == 1:
+    if not args.no_extras and args.type == "bottom-up" and world == 1:
         # the SAH builder (the reference's default --type) on the same triangles: build time only here, so that every
         # trace_kernel launch of the default command stays the headline workload; `--type sah` traces through it
         sinp = rt.BuildInput.allocate(tris, sah=True)
@@ -225,7 +226,7 @@ def main():
             ts.append(e0.elapsed_time(e1))
         extras["sah_build_ms"] = round(statistics.median(ts), 4)
         del sinp
-    if not args.no_extras and not sah and world == 1:
+    if not args.no_extras and args.type == "bottom-up" and world == 1:
         # (1) rebuild + trace per frame as one HIP graph (nothing in that path synchronises or allocates);
         # (2) an on-box stream ceiling (device-to-device copy, read + write bytes) beside the 8 TB/s spec figure
         try:
@@ -273,7 +274,7 @@ def main():
     if rank == 0:
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "trace_traffic.json")
-        if os.path.exists(tpath) and world == 1 and cam == "a" and (W, H, G, args.spp) == (1920, 1080, 708, 1) and not sah:
+        if os.path.exists(tpath) and world == 1 and cam == "a" and (W, H, G, args.spp) == (1920, 1080, 708, 1) and args.type == "bottom-up":
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
@@ -285,7 +286,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"grid_mesh(G={G}, seed=1) = {n} triangles, {W}x{H}, {args.spp} spp, camera "
                                    f"{cam.upper()} ({'top-down' if cam == 'a' else 'oblique'}), render_type {args.render_type}; "
-                                   + ("LBVH" if not sah else "SAH tree" + (" with triangle pairs" if args.type == "sah-pairs" else ""))
+                                   + ({"bottom-up": "LBVH", "hybrid": "LBVH + SAH top tree (hybrid)", "sah": "SAH tree",
+                                      "sah-pairs": "SAH tree with triangle pairs"}[args.type])
                                    + " replicated per GPU",
                        "parallelism": f"row-bands x{world}" + (" + RCCL gather to rank 0, double-buffered frames" if world > 1 else "")},
             "box_tests_per_ray": round(box / rays, 2), "tri_tests_per_ray": round(tri / rays, 3),
