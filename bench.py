@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--type", choices=["bottom-up", "hybrid", "sah", "sah-pairs"], default="bottom-up",
                     help="tree the rays are traced through: the LBVH of the headline metric (default) or the SAH tree "
                          "(rt_run_sah_build, the reference's default --type; reported as a separate workload)")
+    ap.add_argument("--inflight", type=int, default=8,
+                    help="frames in flight: step i is launched on HIP stream i mod INFLIGHT into its own frame buffer, so "
+                         "the next frame's waves fill the CUs the previous frame's last waves leave idle (1 = serial)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the build timing")
     ap.add_argument("--other-camera", action="store_true",
@@ -122,10 +125,14 @@ def main():
 
     cams = {"a": scenes.camera_a(G), "b": scenes.camera_b(G)}
     cam_dev = {k: rt.to_device(v) for k, v in cams.items()}
-    # two frame buffers: with N > 1 the gather of frame i overlaps the trace of frame i+1 (double-buffered frames)
-    frames = [torch.zeros(H * W * 4, dtype=torch.uint8, device="cuda") for _ in range(2 if world > 1 else 1)]
+    # INFLIGHT frame buffers, one HIP stream each: a traced frame is ~4.5 rounds of waves (one band of an 8-GPU run
+    # is less than one), so a launch ends with CUs idling behind its slowest waves; with several frames in flight the
+    # next frame's waves take those CUs (and with N > 1 the gather of frame i overlaps the trace of frame i+1)
+    S = max(1, args.inflight)
+    frames = [torch.zeros(H * W * 4, dtype=torch.uint8, device="cuda") for _ in range(S)]
+    streams = [torch.cuda.Stream() for _ in range(S)]
     frame = frames[0]
-    pending = [None, None]
+    pending = [None] * S
     counters = torch.zeros(4, dtype=torch.int64, device="cuda")
 
     # row bands: rank r renders rows [r*H/N, (r+1)*H/N)  (gpu-raytracing_amd/sharding.py)
@@ -135,28 +142,33 @@ def main():
     step_no = [0]
 
     def step(cam_key, with_counters=False, events=None):
-        k = step_no[0] % len(frames)
+        k = step_no[0] % S
         step_no[0] += 1
-        if pending[k] is not None:          # the gather that last used this buffer must have completed
-            pending[k].wait()
-            pending[k] = None
-        if events is not None:
-            events[0].record()
-        rt.Trace(inp.triangles_out, inp.nodes_out, frames[k], (W, H), cam_dev[cam_key], ROOT_IDX, ROOT_CNT,
-                 render_type=args.render_type, counters=counters if with_counters else None,
-                 rows=(y0, y1), spp=args.spp)
-        if events is not None:
-            events[1].record()
-        if world > 1:
-            pending[k] = sharding.gather_bands(frames[k], W, H, world, rank, dist, async_op=True)
-
-    def drain():
-        for k in range(len(pending)):
-            if pending[k] is not None:
+        with torch.cuda.stream(streams[k]):
+            if pending[k] is not None:          # the gather that last used this buffer must have completed
                 pending[k].wait()
                 pending[k] = None
+            if events is not None:
+                events[0].record()
+            rt.Trace(inp.triangles_out, inp.nodes_out, frames[k], (W, H), cam_dev[cam_key], ROOT_IDX, ROOT_CNT,
+                     render_type=args.render_type, counters=counters if with_counters else None,
+                     rows=(y0, y1), spp=args.spp)
+            if events is not None:
+                events[1].record()
+            if world > 1:
+                pending[k] = sharding.gather_bands(frames[k], W, H, world, rank, dist, async_op=True)
+
+    def drain():
+        for k in range(S):
+            with torch.cuda.stream(streams[k]):
+                if pending[k] is not None:
+                    pending[k].wait()
+                    pending[k] = None
+            streams[k].synchronize()
 
     def timed(cam_key, steps, warmup):
+        for k in range(S):
+            streams[k].wait_stream(torch.cuda.current_stream())
         for _ in range(warmup):
             step(cam_key)
         drain()
@@ -165,8 +177,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        noev = os.environ.get("RT_BENCH_NOEVENTS") == "1"     # (experiment: cost of the per-launch event pairs)
         for i in range(steps):
-            step(cam_key, events=evs[i])
+            step(cam_key, events=None if noev else evs[i])
         drain()                              # every gather of the K timed frames has completed
         if world > 1:
             dist.barrier()
@@ -176,11 +189,12 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        kern_ms = statistics.mean(a.elapsed_time(b) for a, b in evs)
+        kern_ms = dt / steps * 1e3 if noev else statistics.mean(a.elapsed_time(b) for a, b in evs)
         return dt, kern_ms
 
     def test_counts(cam_key):
         counters.zero_()
+        torch.cuda.synchronize()
         step(cam_key, with_counters=True)
         drain()
         torch.cuda.synchronize()
@@ -203,6 +217,22 @@ def main():
     lbox, ltri = int(counters[0].item()), int(counters[1].item())
     alg_bytes = 32 * lbox + 64 * ltri + 4 * W * (y1 - y0)
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    # the same launch with the GPU to itself (one stream, serial): the duration the kernel's own quality is judged by.
+    # Launched as another instantiation of the kernel (kBoxtests <-> kDepth: same rays, same traversal, a different
+    # one-line colour conversion) so that a profiler's per-kernel average for the timed region's kernel name is not
+    # mixed with these serial launches.
+    iso_rt = 1 if args.render_type == 0 else 0
+    iso = []
+    for _ in range(8):
+        e0, e1 = ev(), ev()
+        e0.record()
+        rt.Trace(inp.triangles_out, inp.nodes_out, frame, (W, H), cam_dev[cam], ROOT_IDX, ROOT_CNT, render_type=iso_rt,
+                 rows=(y0, y1), spp=args.spp)
+        e1.record()
+        e1.synchronize()
+        iso.append(e0.elapsed_time(e1))
+    kern_iso_ms = statistics.median(iso)
+    achieved_iso = alg_bytes / (kern_iso_ms * 1e-3) / 1e9
 
     extras = {}
     if not args.no_extras:
@@ -235,11 +265,13 @@ def main():
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.stream(side):
                 build()
-                rt.Trace(inp.triangles_out, inp.nodes_out, frame, (W, H), cam_dev[cam], ROOT_IDX, ROOT_CNT, rows=(y0, y1), spp=args.spp)
+                rt.Trace(inp.triangles_out, inp.nodes_out, frame, (W, H), cam_dev[cam], ROOT_IDX, ROOT_CNT, render_type=iso_rt,
+                         rows=(y0, y1), spp=args.spp)
                 side.synchronize()
                 with torch.cuda.graph(gr, stream=side):
                     build()
-                    rt.Trace(inp.triangles_out, inp.nodes_out, frame, (W, H), cam_dev[cam], ROOT_IDX, ROOT_CNT, rows=(y0, y1), spp=args.spp)
+                    rt.Trace(inp.triangles_out, inp.nodes_out, frame, (W, H), cam_dev[cam], ROOT_IDX, ROOT_CNT, render_type=iso_rt,
+                             rows=(y0, y1), spp=args.spp)
             torch.cuda.current_stream().wait_stream(side)
             gr.replay()
             torch.cuda.synchronize()
@@ -289,19 +321,27 @@ def main():
                                    + ({"bottom-up": "LBVH", "hybrid": "LBVH + SAH top tree (hybrid)", "sah": "SAH tree",
                                       "sah-pairs": "SAH tree with triangle pairs"}[args.type])
                                    + " replicated per GPU",
-                       "parallelism": f"row-bands x{world}" + (" + RCCL gather to rank 0, double-buffered frames" if world > 1 else "")},
+                       "parallelism": f"row-bands x{world}, {S} frames in flight on {S} HIP streams"
+                                      + (" + RCCL gather to rank 0 per frame" if world > 1 else "")},
             "box_tests_per_ray": round(box / rays, 2), "tri_tests_per_ray": round(tri / rays, 3),
             "wave_steps": {"box_phase": wsteps_box, "leaf_phase": wsteps_leaf,
                            "lane_utilisation_box_phase": round(box / 2 / max(wsteps_box, 1) / 64, 3)},
             "roofline": {"bound": "hbm", "kernel": "trace_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(kern_ms, 4),
+                         "launches_in_flight": S,
+                         "isolated_launch": {"kernel_ms": round(kern_iso_ms, 4), "achieved": round(achieved_iso, 1),
+                                             "frac": round(achieved_iso / HBM_PEAK_GBS, 4),
+                                             "kernel": f"trace_kernel<{iso_rt}> (same rays; serial, one stream)"},
                          "formula": "32*sum(box_tests) + 64*sum(tri_tests) + 4*W*rows",
                          # the same bytes against the path that does bound the kernel: per-CU vector L1, 64 B/clk/CU
-                         "l1_path": {"achieved": round(achieved, 1), "peak": round(256 * 64 * 2.4, 1), "unit": "GB/s",
-                                     "frac": round(achieved / (256 * 64 * 2.4), 4),
+                         "l1_path": {"achieved": round(achieved_iso, 1), "peak": round(256 * 64 * 2.4, 1), "unit": "GB/s",
+                                     "frac": round(achieved_iso / (256 * 64 * 2.4), 4),
                                      "peak_formula": "256 CUs x 64 B/clk x 2.4 GHz"},
-                         "note": "frac > 1: the 128 MB BVH is cache resident (HBM traffic = `traffic`); the measured "
+                         "note": "kernel_ms is the mean start-to-end time of the launches of the timed region, of which "
+                                 "`launches_in_flight` run concurrently on separate streams (each takes longer, together they "
+                                 "finish sooner: ms_per_step); `isolated_launch` is the same launch alone on the GPU.  "
+                                 "frac > 1 there: the 128 MB BVH is cache resident (HBM traffic = `traffic`); the measured "
                                  "limiter is the per-CU L1 path: TA busy 75 %, TCP active 87 % (profiles/r01_trace_l1_pmc.txt)"},
         }
         out.update(extras)
