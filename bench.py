@@ -177,9 +177,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        noev = os.environ.get("RT_BENCH_NOEVENTS") == "1"     # (experiment: cost of the per-launch event pairs)
         for i in range(steps):
-            step(cam_key, events=None if noev else evs[i])
+            step(cam_key, events=evs[i])
         drain()                              # every gather of the K timed frames has completed
         if world > 1:
             dist.barrier()
@@ -189,7 +188,7 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        kern_ms = dt / steps * 1e3 if noev else statistics.mean(a.elapsed_time(b) for a, b in evs)
+        kern_ms = statistics.mean(a.elapsed_time(b) for a, b in evs)
         return dt, kern_ms
 
     def test_counts(cam_key):
