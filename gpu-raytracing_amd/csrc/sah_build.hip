@@ -1147,44 +1147,56 @@ __global__ __launch_bounds__(kSmallWaves * 64) void sah_small_kernel(SahArgs a, 
 #pragma unroll
         for (int q = 0; q < 8; q++) bn[q] = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(binned && bin == q) & segmask);
         wave_lds_sync();
-        // ---- SelectPlane (SharedTaskBuilder.cu:297-350) by the first lane of each sub-task
-        if (leader) {
-            uint32_t kind = 2, plane = 0, nl = count >> 1;
-            if (binned) {
-                float sa_l[7];
-                uint32_t ln[7];
+        // ---- SelectPlane (SharedTaskBuilder.cu:297-350): the sub-task's first lane sweeps the bins left -> right, its
+        // second lane right -> left -- the SAME instructions on two lanes (a sub-task here has >= 3 lanes) -- then the
+        // first lane fetches the suffix values and scores the 7 planes (strict <, planes 6 -> 0: the highest wins ties).
+        {
+            const bool fwd = leader && binned, bwd = active && binned && lane == s + 1;
+            float sa_run[7];
+            uint32_t n_run[7];
+            if (fwd || bwd) {
                 int run[6] = {kEmptyLo, kEmptyLo, kEmptyLo, kEmptyHi, kEmptyHi, kEmptyHi};
                 uint32_t cc = 0;
 #pragma unroll
                 for (int i = 0; i < 7; i++) {
-                    ibox_merge(run, &S.bins[seg][i][0]);
-                    cc += bn[i];
+                    const int bi = bwd ? 7 - i : i;
+                    ibox_merge(run, &S.bins[seg][bi][0]);
+                    cc += bwd ? bn[7 - i] : bn[i];
                     float f[6];
                     ibox_to_float(run, f);
-                    sa_l[i] = sah_sa(f);
-                    ln[i] = cc;
+                    sa_run[i] = sah_sa(f);
+                    n_run[i] = cc;
                 }
+            } else {
 #pragma unroll
-                for (int k = 0; k < 6; k++) run[k] = S.bins[seg][7][k];
-                uint32_t rn = bn[7];
-                float best = 3.402823466e+38f;
-                int pl = -1;
-#pragma unroll
-                for (int i = 6; i >= 0; i--) {
-                    float f[6];
-                    ibox_to_float(run, f);
-                    const float score = sa_l[i] * (float)ln[i] + sah_sa(f) * (float)rn;
-                    if (score < best && ln[i] && rn) { best = score; pl = i; nl = ln[i]; }
-                    ibox_merge(run, &S.bins[seg][i][0]);
-                    rn += bn[i];
-                }
-                if (pl >= 0) { kind = 1; plane = (uint32_t)pl; } else nl = count >> 1;
+                for (int i = 0; i < 7; i++) { sa_run[i] = 0.0f; n_run[i] = 0; }
             }
-            S.skind[s] = kind; S.splane[s] = plane; S.snl[s] = nl;
-            // parent descriptor (SharedTaskBuilder.cu:544-558)
-            float pb[6];
-            ibox_to_float(&S.sbox[cur][s][0], pb);
-            sah_put_node(a.nodes + parent, pb, (uint32_t)(bias + 2 * (int)(base + s + nl)), 2u, RT_CHILD_BOX);
+            // suffix j (bins 7 .. 7-j) from the next lane
+            float sa_suf[7];
+            uint32_t n_suf[7];
+#pragma unroll
+            for (int i = 0; i < 7; i++) {
+                sa_suf[i] = __shfl_down(sa_run[i], 1, 64);
+                n_suf[i] = __shfl_down(n_run[i], 1, 64);
+            }
+            if (leader) {
+                uint32_t kind = 2, plane = 0, nl = count >> 1;
+                if (binned) {
+                    float best = 3.402823466e+38f;
+                    int pl = -1;
+#pragma unroll
+                    for (int i = 6; i >= 0; i--) {
+                        const float score = sa_run[i] * (float)n_run[i] + sa_suf[6 - i] * (float)n_suf[6 - i];
+                        if (score < best && n_run[i] && n_suf[6 - i]) { best = score; pl = i; nl = n_run[i]; }
+                    }
+                    if (pl >= 0) { kind = 1; plane = (uint32_t)pl; } else nl = count >> 1;
+                }
+                S.skind[s] = kind; S.splane[s] = plane; S.snl[s] = nl;
+                // parent descriptor (SharedTaskBuilder.cu:544-558)
+                float pb[6];
+                ibox_to_float(&S.sbox[cur][s][0], pb);
+                sah_put_node(a.nodes + parent, pb, (uint32_t)(bias + 2 * (int)(base + s + nl)), 2u, RT_CHILD_BOX);
+            }
         }
         wave_lds_sync();
         // ---- PartitionIds (:352-380), stable; child boxes; move the items
