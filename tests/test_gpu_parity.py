@@ -247,3 +247,24 @@ def test_build_and_trace_capture_in_a_hip_graph(rt, scenes, ora):
         img, oc = ora.trace(o["leaves"], o["nodes"], 0, 2, scenes.camera_b(30), w, h)
         assert (frame.cpu().numpy().reshape(h, w, 4) == img).all()
         assert (counters.cpu().numpy()[:2].astype(np.uint64) == oc[:2]).all()
+
+
+def test_full_size_10m_build(rt, scenes, ora):
+    """BASELINE config 4 (grid G=2237, 10,008,338 triangles, builder-bound): the LBVH bit for bit against the oracle,
+    plus the size-independent properties (sorted, stable, the reference's compiled checker over all 20M slots)."""
+    from helpers import gpu_build, assert_nodes_equal
+    tris = scenes.grid_mesh(2237, 1)
+    n = tris.shape[0]
+    assert n == 10008338
+    g = gpu_build(tris)
+    assert (np.diff(g["codes"].astype(np.int64)) >= 0).all(), "codes sorted"
+    eq = g["codes"][1:] == g["codes"][:-1]
+    assert (g["indices"][1:][eq] > g["indices"][:-1][eq]).all(), "stable within equal codes"
+    assert ora.count_nodes(g["nodes"], 0, 2) == (2 * n - 2, n, n - 2)
+    assert ora.verify_hierarchy(g["nodes"], 0, 2) == 0
+    if ora.ref_available():
+        assert ora.ref_verify_hierarchy(g["nodes"], 0, 2) == ""
+    o = ora.build_bvh(tris)
+    assert (g["codes"] == o["codes"]).all() and (g["indices"] == o["indices"]).all()
+    assert_nodes_equal(g["nodes"], o["nodes"], "10M")
+    assert g["leaves"].tobytes() == o["leaves"].tobytes()

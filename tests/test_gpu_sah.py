@@ -134,3 +134,18 @@ def test_sah_tiny_trees_trace(count, rt, scenes, ora):
     bu = gpu_build(tris)
     f0, _ = gpu_trace(bu, cam, 128, 96, 0)
     assert (f0 == f1).all()
+
+
+def test_sah_10m_bit_exact(rt, scenes, ora):
+    """10,008,338 triangles (BASELINE config 4's scene) through the SAH builder: bit-exact against the oracle."""
+    from helpers import assert_nodes_equal
+    tris = scenes.grid_mesh(2237, 1)
+    g = _gpu_sah(rt, tris, False)
+    o = ora.build_sah(tris)
+    assert g["L"] == o["L"] == tris.shape[0]
+    assert (g["cells"] == o["cell_counts"]).all()
+    assert_nodes_equal(g["nodes"], o["nodes"], "10M sah")
+    assert g["leaves"].tobytes() == o["leaves"].tobytes()
+    L = g["L"]
+    assert ora.count_nodes(g["nodes"], 0, 1) == (2 * L - 1, L, L - 1)
+    assert ora.verify_hierarchy(g["nodes"], 0, 1) == 0
