@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--camera", choices=["a", "b"], default="a")
     ap.add_argument("--render-type", type=int, default=0)
     ap.add_argument("--build-reps", type=int, default=10)
-    ap.add_argument("--type", choices=["bottom-up", "hybrid", "sah", "sah-pairs"], default="bottom-up",
+    ap.add_argument("--type", choices=["bottom-up", "bottom-up-pairs", "hybrid", "sah", "sah-pairs"], default="bottom-up",
                     help="tree the rays are traced through: the LBVH of the headline metric (default) or the SAH tree "
                          "(rt_run_sah_build, the reference's default --type; reported as a separate workload)")
     ap.add_argument("--inflight", type=int, default=8,
@@ -102,6 +102,8 @@ def main():
     def build():
         if sah:
             rt.RunSahBuild(inp, sah_args)
+        elif args.type == "bottom-up-pairs":
+            rt.RunBottomUpBuild(inp, rt.Arguments(build_type=rt.kBottomUp, enable_pairs=True))
         else:
             rt.RunBottomUpBuild(inp, hybrid=hybrid)
 
@@ -317,7 +319,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"grid_mesh(G={G}, seed=1) = {n} triangles, {W}x{H}, {args.spp} spp, camera "
                                    f"{cam.upper()} ({'top-down' if cam == 'a' else 'oblique'}), render_type {args.render_type}; "
-                                   + ({"bottom-up": "LBVH", "hybrid": "LBVH + SAH top tree (hybrid)", "sah": "SAH tree",
+                                   + ({"bottom-up": "LBVH", "bottom-up-pairs": "LBVH with triangle pairs", "hybrid": "LBVH + SAH top tree (hybrid)", "sah": "SAH tree",
                                       "sah-pairs": "SAH tree with triangle pairs"}[args.type])
                                    + " replicated per GPU",
                        "parallelism": f"row-bands x{world}, {S} frames in flight on {S} HIP streams"
