@@ -3,6 +3,7 @@
 #include <cstring>
 #include <exception>
 
+#include "Arguments.h"
 #include "Camera.h"
 #include "FileIO.h"
 #include "Utilities.h"
@@ -65,6 +66,22 @@ void rth_initialise_camera(rt_camera* cam, const float aabb[6])
     InitialiseCamera(*cam, b);
 }
 void rth_update_camera(rt_camera* cam) { UpdateCamera(*cam); }
+// keys: bit 0..6 = w, a, s, d, q, e, space (Input.cuh:4-15)
+void rth_camera_move(rt_camera* cam, unsigned keys)
+{
+    InputState in;
+    in.key_pressed_w = keys & 1; in.key_pressed_a = keys & 2; in.key_pressed_s = keys & 4; in.key_pressed_d = keys & 8;
+    in.key_pressed_q = keys & 16; in.key_pressed_e = keys & 32; in.key_pressed_space = keys & 64;
+    UpdateCameraPosition(*cam, in);
+}
+void rth_camera_look(rt_camera* cam, float dx, float dy) { UpdateCameraLookDelta(*cam, dx, dy); }
+void rth_camera_zoom(rt_camera* cam, int dir) { UpdateCameraZoom(*cam, dir); }
+// ParseCmd (Arguments.cpp:47-63): out = {build_type, enable_splits, enable_pairs, render_type}
+void rth_parse_cmd(int argc, char** argv, int out[4])
+{
+    const Arguments a = ParseCmd(argc, argv);
+    out[0] = (int)a.build_type; out[1] = a.enable_splits; out[2] = a.enable_pairs; out[3] = (int)a.render_type;
+}
 
 void rth_count_nodes(rt_node* nodes, unsigned root, unsigned count, int out[3])
 {

@@ -280,3 +280,77 @@ def ref_verify_hierarchy(nodes: np.ndarray, root: int, count: int) -> str:
             os.close(saved)
         tmp.seek(0)
         return tmp.read().decode(errors="replace")
+
+
+# ---------------------------------------------------------------- the reference's camera and argument parser (oracle/_ref)
+class _InputState(ctypes.Structure):  # Input.cuh:4-15
+    _fields_ = [(k, ctypes.c_bool) for k in ("w", "a", "s", "d", "q", "e", "space", "mouse_down")] + \
+               [("prev_x", ctypes.c_int), ("prev_y", ctypes.c_int)]
+
+
+class _AABB(ctypes.Structure):
+    _fields_ = [("v", ctypes.c_float * 6)]
+
+
+class _RefArguments(ctypes.Structure):  # Arguments.h:28-33
+    _fields_ = [("build_type", ctypes.c_int), ("enable_splits", ctypes.c_bool), ("enable_pairs", ctypes.c_bool),
+                ("render_type", ctypes.c_int)]
+
+
+def ref_camera_available() -> bool:
+    return os.path.exists(os.path.join(_HERE, "_ref", "libref_camera.so"))
+
+
+def _refcam():
+    R = ctypes.CDLL(os.path.join(_HERE, "_ref", "libref_camera.so"))
+    vp = ctypes.c_void_p
+    R.update = getattr(R, "_Z12UpdateCameraR6Camera"); R.update.argtypes = [vp]
+    R.init = getattr(R, "_Z16InitialiseCameraR6Camera4AABB"); R.init.argtypes = [vp, _AABB]
+    R.zoom = getattr(R, "_Z16UpdateCameraZoomR6Camerai"); R.zoom.argtypes = [vp, ctypes.c_int]
+    R.move = getattr(R, "_Z20UpdateCameraPositionR6Camera10InputState"); R.move.argtypes = [vp, _InputState]
+    R.look = getattr(R, "_Z21UpdateCameraLookDeltaR6Cameraff"); R.look.argtypes = [vp, ctypes.c_float, ctypes.c_float]
+    return R
+
+
+def ref_update_camera(cam: np.ndarray) -> np.ndarray:
+    """Camera.cu:8-29 (the reference's own code): cam is a 64-byte Camera record; returns the updated copy."""
+    c = np.ascontiguousarray(cam).copy()
+    _refcam().update(_p(c))
+    return c
+
+
+def ref_initialise_camera(aabb) -> np.ndarray:
+    """Camera.cu:62-91"""
+    c = np.zeros(64, np.uint8)
+    box = _AABB()
+    for k in range(6):
+        box.v[k] = float(aabb[k])
+    _refcam().init(_p(c), box)
+    return c
+
+
+def ref_camera_controls(cam: np.ndarray, keys=(), look=None, zoom=None) -> np.ndarray:
+    """UpdateCameraPosition / UpdateCameraLookDelta / UpdateCameraZoom (Camera.cu:31-60) in that order."""
+    c = np.ascontiguousarray(cam).copy()
+    R = _refcam()
+    if keys:
+        st = _InputState()
+        for k in keys:
+            setattr(st, k, True)
+        R.move(_p(c), st)
+    if look is not None:
+        R.look(_p(c), ctypes.c_float(look[0]), ctypes.c_float(look[1]))
+    if zoom is not None:
+        R.zoom(_p(c), int(zoom))
+    return c
+
+
+def ref_parse_cmd(argv) -> tuple:
+    """Arguments.cpp:47-63 ParseCmd (the reference's own code): returns (build_type, enable_splits, enable_pairs, render_type)."""
+    R = ctypes.CDLL(os.path.join(_HERE, "_ref", "libref_arguments.so"))
+    f = getattr(R, "_Z8ParseCmdiPPc")
+    f.restype = _RefArguments
+    f.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p)]
+    arr = (ctypes.c_char_p * len(argv))(*[a.encode() for a in argv])
+    a = f(len(argv), arr)
+    return int(a.build_type), bool(a.enable_splits), bool(a.enable_pairs), int(a.render_type)

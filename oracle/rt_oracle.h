@@ -16,7 +16,10 @@
  * arithmetic of Morton codes / sort / traversal is "parity unpinned" against reference-held
  * vectors.  What IS pinned: (1) the reference's own structural check -- VerifyHierarchy and
  * CountNodes from Utilities.cpp compiled unmodified into oracle/_ref -- is run on the oracle's
- * (and the GPU's) Node arrays, for the bottom-up, hybrid, pairs and SAH trees alike; (2) the
+ * (and the GPU's) Node arrays, for the bottom-up, hybrid, pairs and SAH trees alike; Camera.cu
+ * (host functions only) and Arguments.cpp are compiled the same way and pin the camera basis every
+ * parity test uses and the host mirror's UpdateCamera / InitialiseCamera / controls / ParseCmd byte
+ * for byte (tests/test_host_mirror.py); (2) the
  * node-count identities of SURVEY.md Appendix A; (3) trees of the same triangles are checked
  * against each other (the SAH and hybrid trees render the same kDepth frame as the LBVH).
  * The hybrid, pairs and SAH builders of the reference number nodes / leaves by atomic arrival

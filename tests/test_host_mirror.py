@@ -106,3 +106,58 @@ def test_unreadable_texture_keeps_material_untextured(host, tmp_path):
     (tmp_path / "a.mtl").write_text("newmtl m\nKd 1 0 0\nmap_Kd missing.png\n")
     s = host.LoadOBJFromFile(str(tmp_path / "a.obj"))
     assert len(s["textures"]) == 0 and s["materials"]["texture"][-1] == -1
+
+
+# ---------------------------------------------------------------- pinned against the reference's own code (oracle/_ref)
+def _hostlib():
+    import ctypes
+    return ctypes.CDLL(os.path.join(HERE, "..", "gpu-raytracing_amd", "host", "librt_host.so"))
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(HERE, "..", "oracle", "_ref", "libref_camera.so")),
+                    reason="oracle/_ref/libref_camera.so (the reference's Camera.cu compiled as C++) is not built")
+def test_camera_mirror_matches_the_reference_code(host, ora, scenes):
+    """host/Camera.cpp against Camera.cu itself (compiled unmodified into oracle/_ref): UpdateCamera, InitialiseCamera
+    and the three interactive controls, byte for byte over a sweep of angles and inputs.  This pins the camera every
+    parity test uses (scenes.make_camera is checked against the same code below)."""
+    import ctypes
+    H = _hostlib()
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        cam = np.zeros(1, host._pkg.CAMERA)
+        cam["position"] = rng.uniform(-50, 50, 3).astype(np.float32)
+        cam["yaw"], cam["pitch"] = np.float32(rng.uniform(-4, 4)), np.float32(rng.uniform(-1.55, 1.55))
+        cam["scale"], cam["max_depth"] = np.float32(rng.uniform(0.1, 5)), np.float32(100)
+        mine = host.UpdateCamera(cam)
+        ref = ora.ref_update_camera(cam)
+        assert mine.tobytes() == ref.tobytes()
+        # scenes.make_camera (numpy float32 sin / cos) produces the same basis
+        py = scenes.make_camera(cam["position"][0], float(cam["yaw"][0]), float(cam["pitch"][0]), 100.0, float(cam["scale"][0]))
+        for f in ("u", "v", "w"):
+            assert np.abs(py[f] - ref.view(host._pkg.CAMERA)[f]).max() <= 2e-7
+        keys = int(rng.integers(0, 128))
+        a, b = mine.copy(), ref.copy()
+        H.rth_camera_move(a.ctypes.data_as(ctypes.c_void_p), keys)
+        b = ora.ref_camera_controls(b, keys=[k for i, k in enumerate(("w", "a", "s", "d", "q", "e", "space")) if keys >> i & 1])
+        dx, dy = float(rng.uniform(-30, 30)), float(rng.uniform(-30, 30))
+        H.rth_camera_look(a.ctypes.data_as(ctypes.c_void_p), ctypes.c_float(dx), ctypes.c_float(dy))
+        b = ora.ref_camera_controls(b, look=(dx, dy))
+        z = int(rng.integers(0, 2)) * 2 - 1
+        H.rth_camera_zoom(a.ctypes.data_as(ctypes.c_void_p), z)
+        b = ora.ref_camera_controls(b, zoom=z)
+        assert a.tobytes() == b.tobytes()
+    for box in ([0, 0, 0, 10, 10, 10], [-3, 2, 5, 40, 2.5, 9], [0, 0, 0, 708, 2, 708]):
+        assert host.InitialiseCamera(box).tobytes() == ora.ref_initialise_camera(box).tobytes()
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(HERE, "..", "oracle", "_ref", "libref_arguments.so")),
+                    reason="oracle/_ref/libref_arguments.so (the reference's Arguments.cpp) is not built")
+def test_parse_cmd_matches_the_reference_code(ora):
+    import ctypes
+    H = _hostlib()
+    for argv in (["rt", "a.obj"], ["rt", "a.obj", "--pairs"], ["rt", "a.obj", "--type", "bottom-up", "--splits"],
+                 ["rt", "a.obj", "--type", "hybrid", "--pairs", "--splits"], ["rt", "a.obj", "--type", "sah", "--unknown", "--pairs"]):
+        arr = (ctypes.c_char_p * len(argv))(*[a.encode() for a in argv])
+        out = (ctypes.c_int * 4)()
+        H.rth_parse_cmd(len(argv), arr, out)
+        assert tuple(out) == tuple(int(v) for v in ora.ref_parse_cmd(argv)), argv
