@@ -354,3 +354,44 @@ def ref_parse_cmd(argv) -> tuple:
     arr = (ctypes.c_char_p * len(argv))(*[a.encode() for a in argv])
     a = f(len(argv), arr)
     return int(a.build_type), bool(a.enable_splits), bool(a.enable_pairs), int(a.render_type)
+
+
+# ---------------------------------------------------------------- the reference's Pairing.cuh (oracle/_ref/libref_pairing.so)
+def ref_pairing_available() -> bool:
+    return os.path.exists(os.path.join(_HERE, "_ref", "libref_pairing.so"))
+
+
+def ref_pair_decision(a9: np.ndarray, b9: np.ndarray) -> tuple:
+    """CanFormTrianglePair && ShouldFormTrianglePair (Pairing.cuh:35-58) on two 9-float triangles: (merge, rot_a, rot_b)."""
+    R = ctypes.CDLL(os.path.join(_HERE, "_ref", "libref_pairing.so"))
+    R.ref_pair_decision.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    rot = np.zeros(2, np.int32)
+    m = R.ref_pair_decision(_p(np.ascontiguousarray(a9, np.float32)), _p(np.ascontiguousarray(b9, np.float32)), _p(rot))
+    return bool(m), int(rot[0]), int(rot[1])
+
+
+def ref_create_pair(a9, b9, a_id: int, b_id: int, rot_a: int, rot_b: int) -> np.ndarray:
+    """CreateTrianglePair (Pairing.cuh:60-77): the 64-byte TrianglePair record (pad3, bytes 60..63, is not set by the reference)."""
+    R = ctypes.CDLL(os.path.join(_HERE, "_ref", "libref_pairing.so"))
+    R.ref_create_pair.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_int, ctypes.c_int,
+                                  ctypes.c_void_p]
+    out = np.zeros(64, np.uint8)
+    R.ref_create_pair(_p(np.ascontiguousarray(a9, np.float32)), None if b9 is None else _p(np.ascontiguousarray(b9, np.float32)),
+                      a_id, b_id, rot_a, rot_b, _p(out))
+    return out
+
+
+def ref_struct_layout() -> np.ndarray:
+    """sizeof / offsetof of the reference's Triangle, Node, TrianglePair, Camera, Attributes, AABB (30 ints, see the driver)."""
+    R = ctypes.CDLL(os.path.join(_HERE, "_ref", "libref_pairing.so"))
+    out = np.zeros(30, np.int32)
+    R.ref_struct_layout(_p(out))
+    return out
+
+
+def ref_pack_node(mn, mx, parent: int, count: int, child: int, type_: int) -> np.ndarray:
+    R = ctypes.CDLL(os.path.join(_HERE, "_ref", "libref_pairing.so"))
+    R.ref_pack_node.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_uint] * 4 + [ctypes.c_void_p]
+    out = np.zeros(1, NODE)
+    R.ref_pack_node(_p(np.asarray(mn, np.float32)), _p(np.asarray(mx, np.float32)), parent, count, child, type_, _p(out))
+    return out

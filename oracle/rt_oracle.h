@@ -19,7 +19,9 @@
  * (and the GPU's) Node arrays, for the bottom-up, hybrid, pairs and SAH trees alike; Camera.cu
  * (host functions only) and Arguments.cpp are compiled the same way and pin the camera basis every
  * parity test uses and the host mirror's UpdateCamera / InitialiseCamera / controls / ParseCmd byte
- * for byte (tests/test_host_mirror.py); (2) the
+ * for byte (tests/test_host_mirror.py); Pairing.cuh / Common.cuh, #included by the forwarding
+ * driver oracle/ref_pairing_driver.cpp, pin the pair decisions, the quad-leaf construction and
+ * the layouts of all PODs; (2) the
  * node-count identities of SURVEY.md Appendix A; (3) trees of the same triangles are checked
  * against each other (the SAH and hybrid trees render the same kDepth frame as the LBVH).
  * The hybrid, pairs and SAH builders of the reference number nodes / leaves by atomic arrival

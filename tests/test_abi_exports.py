@@ -54,3 +54,29 @@ def test_pod_layouts(rt):
     cam = rt.CAMERA.fields
     assert (cam["pitch"][1], cam["w"][1], cam["yaw"][1], cam["u"][1], cam["scale"][1], cam["v"][1], cam["max_depth"][1]) == \
         (12, 16, 28, 32, 44, 48, 60)
+
+
+def test_pod_layouts_match_the_reference_headers():
+    """The ABI's PODs against the reference's own struct definitions (Common.cuh compiled by oracle/ref_pairing_driver.cpp):
+    sizes, every field offset, and the Node bit-fields (parent:29 | count:3, child:29 | type:3)."""
+    import importlib, os
+    import numpy as np
+    from oracle import oracle_py as ora
+    if not ora.ref_pairing_available():
+        import pytest
+        pytest.skip("oracle/_ref/libref_pairing.so is not built")
+    rt = importlib.import_module("gpu-raytracing_amd")
+    L = [int(v) for v in ora.ref_struct_layout()]
+    tri, node, pair, cam, att = rt.TRIANGLE, rt.NODE, rt.TRIANGLE_PAIR, rt.CAMERA, rt.ATTRIBUTES
+    off = lambda d, f: d.fields[f][1]
+    assert L[0:4] == [tri.itemsize, off(tri, "v0"), off(tri, "v1"), off(tri, "v2")]
+    assert L[4:7] == [node.itemsize, off(node, "min"), off(node, "max")]
+    assert L[7:16] == [pair.itemsize, off(pair, "v0"), off(pair, "primitive_id_0"), off(pair, "v1"), off(pair, "primitive_id_1"),
+                       off(pair, "v2"), off(pair, "rotations"), off(pair, "v3"), off(pair, "pad3")]
+    assert L[16:25] == [cam.itemsize, off(cam, "position"), off(cam, "pitch"), off(cam, "w"), off(cam, "yaw"), off(cam, "u"),
+                        off(cam, "scale"), off(cam, "v"), off(cam, "max_depth")]
+    assert L[25:29] == [att.itemsize, off(att, "normal"), off(att, "uv"), off(att, "material_id")]
+    assert L[29] == 24
+    n = ora.ref_pack_node([1, 2, 3], [4, 5, 6], 0x1ABCDEF, 5, 0x1234567, 2)
+    assert int(n["w12"][0]) == (0x1ABCDEF | (5 << 29)) and int(n["w28"][0]) == (0x1234567 | (2 << 29))
+    assert n["min"][0].tolist() == [1, 2, 3] and n["max"][0].tolist() == [4, 5, 6]

@@ -290,3 +290,45 @@ def test_sah_oracle_tree_is_valid_and_renders_like_the_lbvh(scene, pairs, splits
         assert (f0 == f1).all()
         if scene == "grid30":
             assert c1[0] < c0[0]
+
+
+def test_pairing_matches_the_reference_code(scenes, ora):
+    """The oracle's pair decision and quad-leaf construction against Pairing.cuh itself (compiled from the reference
+    tree through oracle/ref_pairing_driver.cpp): every rotation of both triangles around a shared edge, winding flips
+    (no shared directed edge), unrelated triangles, and the box-area rule that refuses long thin pairs."""
+    if not ora.ref_pairing_available():
+        pytest.skip("oracle/_ref/libref_pairing.so is not built")
+    rng = np.random.default_rng(5)
+    cases, merged = 0, 0
+    for trial in range(300):
+        p = rng.uniform(-2, 2, (4, 3)).astype(np.float32)
+        if trial % 5 == 0:
+            p[3] = p[2] + (p[1] - p[0]) * np.float32(40.0)          # stretched: ShouldFormTrianglePair says no
+        A = np.stack([p[0], p[1], p[2]])
+        B = np.stack([p[2], p[1], p[3]])                             # shares edge (1, 2), opposite direction
+        if trial % 7 == 0:
+            B = B[::-1].copy()                                       # same winding as A along the edge: no pair
+        if trial % 11 == 0:
+            B = rng.uniform(-2, 2, (3, 3)).astype(np.float32)        # unrelated
+        for ra in range(3):
+            for rb in range(3):
+                a9 = np.roll(A, ra, axis=0).reshape(9)
+                b9 = np.roll(B, rb, axis=0).reshape(9)
+                merge, rot_a, rot_b = ora.ref_pair_decision(a9, b9)
+                tris = np.stack([a9, b9])
+                o = ora.build_pairs(tris)
+                assert (o["L"] == 1) == merge, (trial, ra, rb)
+                if merge:
+                    exp = ora.ref_create_pair(a9, b9, 0, 1, rot_a, rot_b)
+                    assert o["leaves"][0].tobytes()[:60] == exp.tobytes()[:60]
+                    merged += 1
+                else:
+                    for k, t9 in enumerate((a9, b9)):
+                        src = int(o["indices"][k])                   # leaves are in sorted order
+                        exp = ora.ref_create_pair((a9, b9)[src], None, src, 0, 0, 0)
+                        got = o["leaves"][k].tobytes()
+                        assert got[:12] == exp.tobytes()[:12] and got[16:28] == exp.tobytes()[16:28]   # v0, v1
+                        assert got[32:44] == exp.tobytes()[32:44] and got[48:60] == exp.tobytes()[48:60]  # v2, v3 = v2
+                        assert got[12:16] == exp.tobytes()[12:16]                                      # primitive_id_0
+                cases += 1
+    assert cases == 2700 and merged > 1000
