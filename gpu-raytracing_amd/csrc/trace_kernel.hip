@@ -598,7 +598,10 @@ __device__ __forceinline__ void shade_sample(const TraceParams& p, const rt_came
 }
 
 template <int RENDER>
-__global__ __launch_bounds__(kTraceWaves * 64, RT_TRACE_MIN_WAVES) void trace_kernel(TraceParams p)
+// kDepth / kBoxtests / kTriangleTests end in a one-line colour conversion: they fit 64 VGPRs (8 waves per SIMD); the
+// shading of the other render types would spill there, they keep 72 VGPRs (7 waves)
+__global__ __launch_bounds__(kTraceWaves * 64, (RENDER <= 2 || RENDER == kRenderDebugBoxCount) ? RT_TRACE_MIN_WAVES + 1 : RT_TRACE_MIN_WAVES)
+void trace_kernel(TraceParams p)
 {
     __shared__ uint32_t stack_lds[kTraceWaves][kStackLds][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
