@@ -45,13 +45,21 @@ __global__ __launch_bounds__(256) void sort_upsweep_kernel(const uint32_t* __res
         uint32_t idx = base + i * kSortThreads + threadIdx.x;
         k[i] = idx < n ? keys[idx] : 0u;
     }
+    // the tile histogram only needs counts, not ranks.  Spread digits: one LDS atomic per key.  Clustered digits
+    // (sorted, flat or constant input -- lanes would queue on one LDS word): group the lanes with 8 ballots and let
+    // each group's leader add its size.  The wave chooses by looking at how many lanes share the first lane's digit.
 #pragma unroll
     for (int i = 0; i < (int)kSortItems; i++) {
         uint32_t idx = base + i * kSortThreads + threadIdx.x;
         const bool valid = idx < n;
         const uint32_t d = (k[i] >> shift) & (kRadix - 1);
-        const uint64_t m = match_digit8(d, valid);
-        if (valid && lane == __ffsll((unsigned long long)m) - 1) atomicAdd(&h[d], (uint32_t)__popcll(m));
+        const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+        if (__popcll(__ballot(valid && d == d0)) >= 8) {
+            const uint64_t m = match_digit8(d, valid);
+            if (valid && lane == __ffsll((unsigned long long)m) - 1) atomicAdd(&h[d], (uint32_t)__popcll(m));
+        } else if (valid) {
+            atomicAdd(&h[d], 1u);
+        }
     }
     __syncthreads();
     hist[(size_t)threadIdx.x * num_tiles + tile] = h[threadIdx.x];   // no global atomics anywhere in the sort
