@@ -52,7 +52,7 @@ def soup(n: int, seed: int = 7, dup_fraction: float = 0.25, size: float = 0.02) 
     """n small random triangles in the unit cube; `dup_fraction` of them are exact copies of other triangles
     (equal centroids -> equal Morton codes -> exercises the index tie-break of cpl, BottomUpBuilder.cu:34-38)."""
     idx = np.arange(n * 9, dtype=np.uint32)
-    r = (pcg_hash(idx + np.uint32(seed * 0x01000193)) >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
+    r = (pcg_hash(idx + np.uint32((seed * 0x01000193) & 0xFFFFFFFF)) >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
     r = r.reshape(n, 3, 3)
     centre = r[:, 0, :].copy()
     tris = np.empty((n, 3, 3), dtype=np.float32)
@@ -161,7 +161,7 @@ def procedural_texture(sx: int, sy: int, seed: int = 1, kind: str = "checker") -
     x = np.arange(sx, dtype=np.uint32)[None, :]
     y = np.arange(sy, dtype=np.uint32)[:, None]
     with np.errstate(over="ignore"):
-        hsh = pcg_hash(x + np.uint32(0x9E3779B9) * y + np.uint32(seed * 0x01000193))
+        hsh = pcg_hash(x + np.uint32(0x9E3779B9) * y + np.uint32((seed * 0x01000193) & 0xFFFFFFFF))
     if kind == "checker":
         c = (((x // 4) + (y // 4)) & 1).astype(np.uint32)
         r = np.where(c == 1, 220, 40).astype(np.uint32) + (hsh & np.uint32(31))
