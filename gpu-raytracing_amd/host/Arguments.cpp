@@ -4,22 +4,24 @@
 
 std::string g_filename = "";
 
+namespace {
+// the --type spellings of the reference (Arguments.cpp:9-33), one table for both directions
+struct TypeName { const char* name; BuildType type; };
+constexpr TypeName kTypeNames[] = {{"sah", kSAH}, {"bottom-up", kBottomUp}, {"hybrid", kHybrid}};
+
+BuildType TypeFromName(const std::string& s)
+{
+    for (const TypeName& t : kTypeNames)
+        if (s == t.name) return t.type;
+    return kNone;
+}
+}  // namespace
+
 std::string BuildTypeToString(BuildType b)
 {
-    switch (b) {
-    case kHybrid: return "hybrid";
-    case kSAH: return "sah";
-    case kBottomUp: return "bottom-up";
-    default: return "none";
-    }
-}
-
-static BuildType ParseType(const std::string& s)
-{
-    if (s == "hybrid") return kHybrid;
-    if (s == "sah") return kSAH;
-    if (s == "bottom-up") return kBottomUp;
-    return kNone;
+    for (const TypeName& t : kTypeNames)
+        if (t.type == b) return t.name;
+    return "none";
 }
 
 Arguments ParseCmd(int argc, char** argv)
@@ -27,11 +29,12 @@ Arguments ParseCmd(int argc, char** argv)
     Arguments args;
     if (argc >= 2) g_filename = argv[1];
     for (int i = 2; i < argc; i++) {
-        const std::string a = argv[i];
-        if (a == "--pairs") args.enable_pairs = true;
-        else if (a == "--splits") args.enable_splits = true;
-        else if (a == "--type" && i + 1 < argc) args.build_type = ParseType(argv[++i]);
+        const std::string opt = argv[i];
+        if (opt == "--pairs") args.enable_pairs = true;
+        else if (opt == "--splits") args.enable_splits = true;
+        else if (opt == "--type" && i + 1 < argc) args.build_type = TypeFromName(argv[++i]);
     }
+    // the reference's PrintArgs block (Arguments.cpp:35-40)
     printf("Arguments:\n  BuildType: %s\n  Pairs: %s\n  Splits: %s\n\n", BuildTypeToString(args.build_type).c_str(),
            args.enable_pairs ? "true" : "false", args.enable_splits ? "true" : "false");
     return args;

@@ -1,20 +1,45 @@
-// Arguments.h -- mirrors the reference's Arguments.h:8-37 / Arguments.cpp:42-63.
+// Arguments.h -- the command-line options of the reference (its Arguments.h:8-37, parsed by Arguments.cpp:42-63), kept
+// source compatible for callers (`args.build_type == kHybrid`, `args.enable_pairs` ...) and tied to the C ABI: every
+// enumerator takes its value from include/rt_abi.h, and abi() yields the rt_arguments the library entry points take.
 #pragma once
 #include <string>
 
-extern std::string g_filename;
+#include "rt_abi.h"
 
-enum BuildType { kSAH, kBottomUp, kHybrid, kNone };
-enum RenderType { kDepth = 0, kBoxtests = 1, kTriangleTests = 2, kMaterialId = 3, kLODs = 4, kDiffuse = 5,
-                  kTexture = 6, kTextureLit = 7, kTextureLitShadows = 8, kCount = 9 };
+extern std::string g_filename;   // argv[1], as in the reference
 
-struct Arguments {
-    BuildType build_type = kSAH;   // the reference's default (Arguments.h:29); only kBottomUp / kHybrid are built here
-    bool enable_splits = false;
-    bool enable_pairs = false;
-    RenderType render_type = RenderType::kDepth;
+enum BuildType {
+    kSAH = RT_BUILD_SAH,             // the default, like the reference
+    kBottomUp = RT_BUILD_BOTTOM_UP,
+    kHybrid = RT_BUILD_HYBRID,
+    kNone = RT_BUILD_NONE,
 };
 
-// `<file.obj> [--pairs] [--splits] [--type sah|bottom-up|hybrid]`; unknown --type -> kNone (the reference asserts)
+enum RenderType {
+    kDepth = RT_RENDER_DEPTH,
+    kBoxtests = RT_RENDER_BOXTESTS,
+    kTriangleTests = RT_RENDER_TRIANGLE_TESTS,
+    kMaterialId = RT_RENDER_MATERIAL_ID,
+    kLODs = RT_RENDER_LODS,
+    kDiffuse = RT_RENDER_DIFFUSE,
+    kTexture = RT_RENDER_TEXTURE,
+    kTextureLit = RT_RENDER_TEXTURE_LIT,
+    kTextureLitShadows = RT_RENDER_TEXTURE_LIT_SHADOWS,
+    kCount = RT_RENDER_COUNT,
+};
+
+struct Arguments {
+    BuildType build_type = kSAH;
+    bool enable_splits = false;      // --splits: SAH builds only (RunBottomUpBuild ignores it, as in the reference)
+    bool enable_pairs = false;       // --pairs
+    RenderType render_type = kDepth;
+
+    rt_arguments abi() const
+    {
+        return rt_arguments{(int32_t)build_type, enable_splits ? 1 : 0, enable_pairs ? 1 : 0, (int32_t)render_type};
+    }
+};
+
+// `<file.obj> [--pairs] [--splits] [--type sah|bottom-up|hybrid]`; an unknown --type gives kNone (the reference asserts)
 Arguments ParseCmd(int argc, char** argv);
 std::string BuildTypeToString(BuildType b);

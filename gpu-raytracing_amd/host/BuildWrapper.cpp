@@ -14,7 +14,7 @@ size_t BuMemoryRequirements(uint32_t num_triangles) { return rt_bu_memory_requir
 void RunBottomUpBuild(BuildInput input, Arguments args, bool hybrid, void* stream)
 {
     rt_build_input in{input.triangles_in, input.triangles_out, input.num_triangles, input.nodes_out, input.scratch};
-    rt_arguments a{(int32_t)args.build_type, args.enable_splits ? 1 : 0, args.enable_pairs ? 1 : 0, (int32_t)args.render_type};
+    const rt_arguments a = args.abi();
     const int rc = rt_run_bottom_up_build(&in, &a, hybrid ? 1 : 0, stream);
     if (rc != RT_OK) Die("RunBottomUpBuild", rc);
 }
@@ -24,7 +24,7 @@ size_t SahMemoryRequirements(uint32_t num_triangles) { return rt_sah_memory_requ
 void RunSahBuild(BuildInput input, Arguments args, void* stream)
 {
     rt_build_input in{input.triangles_in, input.triangles_out, input.num_triangles, input.nodes_out, input.scratch};
-    rt_arguments a{(int32_t)args.build_type, args.enable_splits ? 1 : 0, args.enable_pairs ? 1 : 0, (int32_t)args.render_type};
+    const rt_arguments a = args.abi();
     const int rc = rt_run_sah_build(&in, &a, stream);
     if (rc != RT_OK) Die("RunSahBuild", rc);
 }
