@@ -18,7 +18,7 @@ namespace rt {
 // domain (DeviceUtils.cuh:3-13), wave-reduced, block-reduced through LDS and finished with 6 integer
 // atomics per BLOCK (exact, order independent).
 __global__ __launch_bounds__(1024) void scene_aabb_kernel(const float* __restrict__ f, uint64_t nfloats,
-                                                          int* __restrict__ aabb)
+                                                          int* __restrict__ aabb, uint32_t nparts)
 {
     const uint64_t nvec = nfloats >> 2;
     const uint64_t stride = (uint64_t)gridDim.x * 1024;
@@ -70,7 +70,10 @@ __global__ __launch_bounds__(1024) void scene_aabb_kernel(const float* __restric
         const int k = threadIdx.x;
         int v = red[0][k];
         for (int w = 1; w < 16; w++) v = k < 3 ? min(v, red[w][k]) : max(v, red[w][k]);
-        if (k < 3) atomicMin(&aabb[k], v); else atomicMax(&aabb[k], v);   // 6 atomics per workgroup, <= 255 workgroups
+        // 6 atomics per workgroup into partial box (blockIdx mod nparts): same-address device atomics queue at about
+        // 50 ns each, so the build spreads them over kAabbParts copies that the Morton kernel folds
+        int* dst = aabb + 6 * (blockIdx.x % nparts);
+        if (k < 3) atomicMin(&dst[k], v); else atomicMax(&dst[k], v);
     }
 }
 
@@ -98,13 +101,32 @@ __device__ __forceinline__ uint32_t morton3d(float x, float y, float z)
     return expand_bits((uint32_t)x) * 4 + expand_bits((uint32_t)y) * 2 + expand_bits((uint32_t)z);
 }
 
+// the scene box from `nparts` partial boxes (nparts * 6 <= 256 threads take one word each); every thread gets it
+__device__ __forceinline__ void fold_scene_box(const int* __restrict__ parts, uint32_t nparts, int* sbox /* LDS [6] */,
+                                               float* mn, float* mx)
+{
+    if (threadIdx.x < 6) sbox[threadIdx.x] = threadIdx.x < 3 ? 0x7f7fffff : (int)0x80800000;
+    __syncthreads();
+    if (threadIdx.x < nparts * 6) {
+        const int v = parts[threadIdx.x];
+        const uint32_t k = threadIdx.x % 6;
+        if (k < 3) atomicMin(&sbox[k], v); else atomicMax(&sbox[k], v);
+    }
+    __syncthreads();
+    for (int k = 0; k < 3; k++) { mn[k] = ordered_int_to_float(sbox[k]); mx[k] = ordered_int_to_float(sbox[3 + k]); }
+}
+
 // Morton codes: one block = 256 triangles = 2304 floats staged through LDS with coalesced float4
 // loads; each thread then reads its 9 floats at a 9-dword stride (9 is odd: conflict-free).
 __global__ __launch_bounds__(256) void morton_kernel(uint32_t* __restrict__ codes, uint32_t* __restrict__ values,
                                                      const float* __restrict__ f, const int* __restrict__ aabb,
-                                                     uint32_t n)
+                                                     uint32_t n, uint32_t nparts, int* __restrict__ aabb_out)
 {
     __shared__ float s[256 * 9];
+    __shared__ int sbox[6];
+    float bmin[3], bmax[3];
+    fold_scene_box(aabb, nparts, sbox, bmin, bmax);
+    if (aabb_out && blockIdx.x == 0 && threadIdx.x < 6) aabb_out[threadIdx.x] = sbox[threadIdx.x];   // the folded box, for later readers
     const uint64_t nfloats = (uint64_t)n * 9;
     const uint64_t base = (uint64_t)blockIdx.x * (256 * 9);
     const float4* f4 = reinterpret_cast<const float4*>(f + base);  // 9216-byte block stride: 16-B aligned
@@ -130,9 +152,7 @@ __global__ __launch_bounds__(256) void morton_kernel(uint32_t* __restrict__ code
     float cx = ((t[0] + t[3]) + t[6]) / 3.0f;
     float cy = ((t[1] + t[4]) + t[7]) / 3.0f;
     float cz = ((t[2] + t[5]) + t[8]) / 3.0f;
-    const float minx = ordered_int_to_float(aabb[0]), miny = ordered_int_to_float(aabb[1]);
-    const float minz = ordered_int_to_float(aabb[2]), maxx = ordered_int_to_float(aabb[3]);
-    const float maxy = ordered_int_to_float(aabb[4]), maxz = ordered_int_to_float(aabb[5]);
+    const float minx = bmin[0], miny = bmin[1], minz = bmin[2], maxx = bmax[0], maxy = bmax[1], maxz = bmax[2];
     cx = (cx - minx) / (maxx - minx);
     cy = (cy - miny) / (maxy - miny);
     cz = (cz - minz) / (maxz - minz);
@@ -198,9 +218,13 @@ __global__ __launch_bounds__(kPairThreads) void morton_pairs_kernel(uint32_t* __
                                                                     const int* __restrict__ aabb,
                                                                     const uint8_t* __restrict__ flags,
                                                                     const uint32_t* __restrict__ block_offsets,
-                                                                    uint32_t n)
+                                                                    uint32_t n, uint32_t nparts, int* __restrict__ aabb_out)
 {
     __shared__ uint32_t ws[8];
+    __shared__ int sbox[6];
+    float mn[3], mx[3];
+    fold_scene_box(aabb, nparts, sbox, mn, mx);
+    if (aabb_out && blockIdx.x == 0 && threadIdx.x < 6) aabb_out[threadIdx.x] = sbox[threadIdx.x];
     const uint32_t k = blockIdx.x * kPairThreads + threadIdx.x, tid = 2 * k;
     const bool live = tid < n, second_valid = tid + 1 < n;
     const bool merge = live && flags[k] != 0;
@@ -211,8 +235,6 @@ __global__ __launch_bounds__(kPairThreads) void morton_pairs_kernel(uint32_t* __
     float A[9], B[9];
     load_tri9(f + (size_t)tid * 9, A);
     load_tri9(f + (size_t)(second_valid ? tid + 1 : tid) * 9, B);
-    const float mn[3] = {ordered_int_to_float(aabb[0]), ordered_int_to_float(aabb[1]), ordered_int_to_float(aabb[2])};
-    const float mx[3] = {ordered_int_to_float(aabb[3]), ordered_int_to_float(aabb[4]), ordered_int_to_float(aabb[5])};
     float c1[3], c2[3];
 #pragma unroll
     for (int j = 0; j < 3; j++) {
@@ -231,7 +253,8 @@ __global__ __launch_bounds__(kPairThreads) void morton_pairs_kernel(uint32_t* __
 }
 
 hipError_t launch_morton_pairs(uint32_t* codes, uint32_t* values, const rt_triangle* tris, const int* aabb, uint32_t n,
-                               uint8_t* flags, uint32_t* block_sums, uint32_t* num_leaves, hipStream_t st)
+                               uint8_t* flags, uint32_t* block_sums, uint32_t* num_leaves, hipStream_t st, uint32_t nparts,
+                               int* aabb_out)
 {
     const uint32_t cand = (n + 1) / 2;
     const uint32_t blocks = (cand + kPairThreads - 1) / kPairThreads;
@@ -239,7 +262,7 @@ hipError_t launch_morton_pairs(uint32_t* codes, uint32_t* values, const rt_trian
     if (n == 0) { pair_scan_kernel<<<1, 1024, 0, st>>>(block_sums, 0, num_leaves); return hipGetLastError(); }
     pair_flags_kernel<<<blocks, kPairThreads, 0, st>>>(f, n, flags, block_sums);
     pair_scan_kernel<<<1, 1024, 0, st>>>(block_sums, blocks, num_leaves);
-    morton_pairs_kernel<<<blocks, kPairThreads, 0, st>>>(codes, values, f, aabb, flags, block_sums, n);
+    morton_pairs_kernel<<<blocks, kPairThreads, 0, st>>>(codes, values, f, aabb, flags, block_sums, n, nparts, aabb_out);
     return hipGetLastError();
 }
 
@@ -266,23 +289,27 @@ hipError_t launch_reset_aabb(int* aabb, hipStream_t st)
     return hipGetLastError();
 }
 
-hipError_t launch_scene_aabb(const rt_triangle* tris, uint32_t n, int* aabb, hipStream_t st)
+hipError_t launch_scene_aabb(const rt_triangle* tris, uint32_t n, int* aabb, hipStream_t st, uint32_t nparts)
 {
     if (n == 0) return hipSuccess;
     const uint64_t nfloats = (uint64_t)n * 9;
-    // ~4 float4 per thread, at most 255 workgroups of 1024 (one per CU): few same-address atomics at the end
+    // ~4 float4 per thread.  One box (nparts = 1): at most 255 workgroups of 1024, because the 6 final atomics of every
+    // workgroup hit the same words.  nparts partial boxes (each `aabb + 6 * i`, reset by the caller, folded by the
+    // consumer): the chains are nparts times shorter, so twice the workgroups pay off.
     uint64_t want = (nfloats / 16 + 1023) / 1024;
-    uint32_t blocks = (uint32_t)(want < 3 ? 3 : (want > 255 ? 255 : want));
+    const uint32_t cap = nparts > 1 ? 510u : 255u;
+    uint32_t blocks = (uint32_t)(want < 3 ? 3 : (want > cap ? cap : want));
     blocks = blocks / 3 * 3;                                 // multiple of 3 (see kernel comment)
-    scene_aabb_kernel<<<blocks, 1024, 0, st>>>(reinterpret_cast<const float*>(tris), nfloats, aabb);
+    scene_aabb_kernel<<<blocks, 1024, 0, st>>>(reinterpret_cast<const float*>(tris), nfloats, aabb, nparts ? nparts : 1u);
     return hipGetLastError();
 }
 
 hipError_t launch_morton(uint32_t* codes, uint32_t* values, const rt_triangle* tris, const int* aabb, uint32_t n,
-                         hipStream_t st)
+                         hipStream_t st, uint32_t nparts, int* aabb_out)
 {
     if (n == 0) return hipSuccess;
-    morton_kernel<<<(n + 255) / 256, 256, 0, st>>>(codes, values, reinterpret_cast<const float*>(tris), aabb, n);
+    morton_kernel<<<(n + 255) / 256, 256, 0, st>>>(codes, values, reinterpret_cast<const float*>(tris), aabb, n,
+                                                   nparts ? nparts : 1u, aabb_out);
     return hipGetLastError();
 }
 

@@ -27,6 +27,7 @@ BuLayout bu_layout(uint32_t n)
     L.hybrid = off;         off = align_up(off + 64 * 1024, 256);
     L.pair_flags = off;     off = align_up(off + (nn + 1) / 2, 256);
     L.pair_sums = off;      off = align_up(off + ((nn + 1) / 2 / 256 + 2) * 4, 256);
+    L.aabb_parts = off;     off = align_up(off + kAabbParts * 6 * 4, 256);
     L.total = off;
     return L;
 }
@@ -35,10 +36,11 @@ static inline int hip_rc(hipError_t e) { return e == hipSuccess ? RT_OK : RT_ERR
 
 // one launch for the build's tiny initialisations: status words = 0 and the ordered-int "empty" scene box
 // (BuildWrapper.cu:288-303 does these with 6 memset / memcpy calls)
-__global__ void build_init_kernel(uint32_t* status, int* aabb, uint32_t n)
+__global__ void build_init_kernel(uint32_t* status, int* aabb, int* aabb_parts, uint32_t n)
 {
     if (threadIdx.x < 8) status[threadIdx.x] = threadIdx.x == 1 ? n : 0;   // [1] = number of leaves (pairs: overwritten)
     if (threadIdx.x < 6) aabb[threadIdx.x] = threadIdx.x < 3 ? 0x7f7fffff : (int)0x80800000;
+    for (uint32_t i = threadIdx.x; i < kAabbParts * 6; i += blockDim.x) aabb_parts[i] = (i % 6) < 3 ? 0x7f7fffff : (int)0x80800000;
 }
 
 }  // namespace rt
@@ -116,9 +118,10 @@ int rt_run_bottom_up_build(const rt_build_input* input, const rt_arguments* args
     uint32_t* tmpk = reinterpret_cast<uint32_t*>(s + L.tmp_keys);
     uint32_t* tmpv = reinterpret_cast<uint32_t*>(s + L.tmp_vals);
 
-    build_init_kernel<<<1, 64, 0, st>>>(status, p_aabb, n);
+    int* aabb_parts = reinterpret_cast<int*>(s + L.aabb_parts);
+    build_init_kernel<<<1, 64, 0, st>>>(status, p_aabb, aabb_parts, n);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = launch_scene_aabb(input->triangles_in, n, p_aabb, st);
+    if (e == hipSuccess) e = launch_scene_aabb(input->triangles_in, n, aabb_parts, st, kAabbParts);
     // with --pairs the number of leaves L <= n is only known on the device (status[1]); the reference copies it
     // back to the host (BuildWrapper.cu:317-321, a sync) -- here the downstream kernels read it from memory and the
     // grids are sized for n
@@ -126,10 +129,10 @@ int rt_run_bottom_up_build(const rt_build_input* input, const rt_arguments* args
     const uint32_t* n_dev = pairs ? num_leaves : nullptr;
     if (e == hipSuccess) {
         if (pairs)
-            e = launch_morton_pairs(morton, sorted, input->triangles_in, p_aabb, n, reinterpret_cast<uint8_t*>(s + L.pair_flags),
-                                    reinterpret_cast<uint32_t*>(s + L.pair_sums), num_leaves, st);
+            e = launch_morton_pairs(morton, sorted, input->triangles_in, aabb_parts, n, reinterpret_cast<uint8_t*>(s + L.pair_flags),
+                                    reinterpret_cast<uint32_t*>(s + L.pair_sums), num_leaves, st, kAabbParts, p_aabb);
         else
-            e = launch_morton(morton, sorted, input->triangles_in, p_aabb, n, st);
+            e = launch_morton(morton, sorted, input->triangles_in, aabb_parts, n, st, kAabbParts, p_aabb);
     }
     if (e == hipSuccess) e = launch_radix_sort(morton, sorted, tmpk, tmpv, n, s + L.sort, st, n_dev);
     if (e == hipSuccess)

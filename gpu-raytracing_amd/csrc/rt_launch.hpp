@@ -57,6 +57,7 @@ struct BuLayout {
     size_t hybrid;          // hybrid top-tree work area
     size_t pair_flags;      // uint8[(n+1)/2] merge decision per candidate (--pairs)
     size_t pair_sums;       // uint32[ceil((n+1)/2 / 256)] leaf counts / offsets per workgroup (--pairs)
+    size_t aabb_parts;      // int32[kAabbParts][6] partial scene boxes
     size_t total;
 };
 BuLayout bu_layout(uint32_t n);
@@ -73,11 +74,15 @@ SahLayout sah_layout(uint32_t n);
 
 // ---- launches
 hipError_t launch_reset_aabb(int* aabb, hipStream_t st);
-hipError_t launch_scene_aabb(const rt_triangle* tris, uint32_t n, int* aabb, hipStream_t st);
+// scene box: `aabb` holds nparts ordered-int boxes (6 ints each, reset to empty by the caller); workgroup b folds into box
+// b mod nparts.  The Morton kernels fold the nparts boxes and (aabb_out != null) publish the result.
+constexpr uint32_t kAabbParts = 32;
+hipError_t launch_scene_aabb(const rt_triangle* tris, uint32_t n, int* aabb, hipStream_t st, uint32_t nparts = 1);
 hipError_t launch_morton(uint32_t* codes, uint32_t* values, const rt_triangle* tris, const int* aabb, uint32_t n,
-                         hipStream_t st);
+                         hipStream_t st, uint32_t nparts = 1, int* aabb_out = nullptr);
 hipError_t launch_morton_pairs(uint32_t* codes, uint32_t* values, const rt_triangle* tris, const int* aabb, uint32_t n,
-                               uint8_t* flags, uint32_t* block_sums, uint32_t* num_leaves, hipStream_t st);
+                               uint8_t* flags, uint32_t* block_sums, uint32_t* num_leaves, hipStream_t st,
+                               uint32_t nparts = 1, int* aabb_out = nullptr);
 // n_dev (may be null): device word holding the real element count (<= n); n then only sizes the grids
 hipError_t launch_radix_sort(uint32_t* keys, uint32_t* vals, uint32_t* tmp_keys, uint32_t* tmp_vals, uint32_t n,
                              void* sort_scratch, hipStream_t st, const uint32_t* n_dev = nullptr);
