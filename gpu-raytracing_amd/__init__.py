@@ -96,7 +96,7 @@ class _SahScratchLayout(ctypes.Structure):
 EXPORTS = ["rt_bu_memory_requirements", "rt_nodes_bytes", "rt_run_bottom_up_build", "rt_bu_scratch_layout_get",
            "rt_sah_memory_requirements", "rt_run_sah_build", "rt_sah_scratch_layout_get",
            "rt_calculate_scene_aabb", "rt_generate_morton_codes", "rt_radix_sort_scratch_bytes",
-           "rt_radix_sort_u32_pairs", "rt_trace", "rt_error_string", "rt_version_string"]
+           "rt_radix_sort_u32_pairs", "rt_trace", "rt_trace_strips", "rt_error_string", "rt_version_string"]
 
 _lib = None
 
@@ -135,6 +135,8 @@ def lib() -> ctypes.CDLL:
     L.rt_radix_sort_u32_pairs.argtypes = [vp, vp, vp, vp, u32, vp, vp]
     L.rt_trace.restype = i32
     L.rt_trace.argtypes = [ctypes.POINTER(_Accel), ctypes.POINTER(_Scene), vp, i32, vp, u32, u32, u32, u32, u32, vp]
+    L.rt_trace_strips.restype = i32
+    L.rt_trace_strips.argtypes = [ctypes.POINTER(_Accel), ctypes.POINTER(_Scene), vp, i32, vp, u32, u32, u32, u32, u32, u32, vp]
     L.rt_error_string.restype = ctypes.c_char_p
     L.rt_error_string.argtypes = [i32]
     L.rt_version_string.restype = ctypes.c_char_p
@@ -307,11 +309,21 @@ class DeviceTextures:
 
 def Trace(triangles, nodes, rgba8, dims, camera, root: int, count: int, *, render_type: int = kDepth,
           attributes=None, materials=None, num_materials: int = 0, light=(0.0, 0.0, 0.0), counters=None,
-          rows=None, spp: int = 1, stream=None, textures: Optional[DeviceTextures] = None) -> None:
+          rows=None, spp: int = 1, stream=None, textures: Optional[DeviceTextures] = None, strips=None) -> None:
     """main.cu:125-192 Trace(): `camera` is a 64-byte DEVICE buffer, `rgba8` a w*h*4-byte device buffer
-    (the reference writes a GL surface; row 0 first).  rows=(y0, y1) restricts to a row band (multi-GPU tiling)."""
+    (the reference writes a GL surface; row 0 first).  rows=(y0, y1) restricts to a row band (multi-GPU tiling);
+    strips=(strip_rows, first, stride) renders interleaved strips into a COMPACT buffer (rt_trace_strips)."""
     w, h = int(dims[0]), int(dims[1])
     y0, y1 = (0, h) if rows is None else (int(rows[0]), int(rows[1]))
+    if strips is not None:
+        a = _Accel(_ptr(triangles), _ptr(nodes), root, count)
+        s = _Scene(_ptr(attributes), _ptr(materials), _ptr(textures.table) if textures is not None else 0, _ptr(camera),
+                   (ctypes.c_float * 3)(*[float(x) for x in light]),
+                   0, num_materials, textures.count if textures is not None else 0)
+        _check(lib().rt_trace_strips(ctypes.byref(a), ctypes.byref(s), _ptr(counters), render_type, _ptr(rgba8), w, h,
+                                     int(strips[0]), int(strips[1]), int(strips[2]), spp, _stream_ptr(stream)),
+               "rt_trace_strips")
+        return
     a = _Accel(_ptr(triangles), _ptr(nodes), root, count)
     s = _Scene(_ptr(attributes), _ptr(materials), _ptr(textures.table) if textures is not None else 0, _ptr(camera),
                (ctypes.c_float * 3)(*[float(x) for x in light]),

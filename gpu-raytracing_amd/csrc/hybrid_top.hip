@@ -310,11 +310,10 @@ __global__ void hybrid_empty_kernel(rt_node* nodes)
 
 hipError_t launch_hybrid_top(rt_node* nodes, const int* aabb_ordered, uint32_t n, hipStream_t st, const uint32_t* n_dev)
 {
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&hybrid_top_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TopSmem));
+    static PerDeviceOnce once;
+    const hipError_t attr_err = once([] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&hybrid_top_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TopSmem));
     });
     if (attr_err != hipSuccess) return attr_err;
     if (n == 0) hybrid_empty_kernel<<<1, 64, 0, st>>>(nodes);

@@ -356,14 +356,14 @@ hipError_t launch_lbvh_levels(const rt_triangle* tris, const uint32_t* codes, co
                               uint32_t n, rt_triangle_pair* leaves, rt_node* nodes, void* level_scratch,
                               uint32_t* status, hipStream_t st, const uint32_t* n_dev)
 {
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&lbvh_level_kernel<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LevelCfg<false>::kBytes);
-        if (attr_err == hipSuccess)
-            attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&lbvh_level_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LevelCfg<true>::kBytes);
+    static PerDeviceOnce once;
+    const hipError_t attr_err = once([] {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lbvh_level_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LevelCfg<false>::kBytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lbvh_level_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LevelCfg<true>::kBytes);
+        return e;
     });
     if (attr_err != hipSuccess) return attr_err;
 

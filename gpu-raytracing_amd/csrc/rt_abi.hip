@@ -167,19 +167,26 @@ int rt_run_sah_build(const rt_build_input* input, const rt_arguments* args, void
     if ((reinterpret_cast<uintptr_t>(input->scratch) & 255u) || (reinterpret_cast<uintptr_t>(input->triangles_in) & 15u) ||
         (reinterpret_cast<uintptr_t>(input->triangles_out) & 63u) || (reinterpret_cast<uintptr_t>(input->nodes_out) & 63u))
         return RT_ERR_INVALID_ARGUMENT;
-    return hip_rc(launch_sah_build(input->triangles_in, n, args && args->enable_pairs, splits, input->triangles_out, input->nodes_out,
-                                   input->scratch, static_cast<hipStream_t>(stream), nullptr));
+    uint32_t status0 = 0;
+    const hipError_t e = launch_sah_build(input->triangles_in, n, args && args->enable_pairs, splits, input->triangles_out,
+                                          input->nodes_out, input->scratch, static_cast<hipStream_t>(stream), nullptr, &status0);
+    if (e != hipSuccess) return hip_rc(e);
+    return status0 ? RT_ERR_BUILD_INCOMPLETE : RT_OK;
 }
 
-int rt_trace(const rt_accel* as, const rt_scene* scene, uint64_t* counters, int render_type, uint8_t* rgba8,
-             uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t spp, void* stream)
+static int trace_common(const rt_accel* as, const rt_scene* scene, uint64_t* counters, int render_type, uint8_t* rgba8,
+                        uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t spp, uint32_t strip_rows,
+                        uint32_t strip_first, uint32_t strip_stride, void* stream)
 {
     if (!as || !scene || !rgba8 || !as->nodes || !scene->camera) return RT_ERR_INVALID_ARGUMENT;
     if (w == 0 || h == 0 || y0 > y1 || y1 > h || as->count > 7) return RT_ERR_INVALID_ARGUMENT;
     if (spp == 0) spp = 1;
     if (spp != 1 && spp != 4 && spp != 16) return RT_ERR_INVALID_ARGUMENT;
     switch (render_type) {
-    case RT_RENDER_DEPTH: case RT_RENDER_BOXTESTS: case RT_RENDER_TRIANGLE_TESTS: case 100 /* tuning aid: raw box-test count per pixel */: break;
+    case RT_RENDER_DEPTH: case RT_RENDER_BOXTESTS: case RT_RENDER_TRIANGLE_TESTS: break;
+#ifdef RT_TRACE_TUNING
+    case 100: break;   // tuning build only: raw box-test count per pixel
+#endif
     case RT_RENDER_MATERIAL_ID: case RT_RENDER_DIFFUSE:
         if (!scene->attributes || !scene->materials || scene->num_materials == 0) return RT_ERR_INVALID_ARGUMENT;
         break;
@@ -196,7 +203,23 @@ int rt_trace(const rt_accel* as, const rt_scene* scene, uint64_t* counters, int 
     t.render_type = render_type;
     t.rgba8 = rgba8;
     t.w = w; t.h = h; t.y0 = y0; t.y1 = y1; t.spp = spp;
+    t.strip_rows = strip_rows; t.strip_first = strip_first; t.strip_stride = strip_stride;
     return hip_rc(launch_trace(t, static_cast<hipStream_t>(stream)));
+}
+
+int rt_trace(const rt_accel* as, const rt_scene* scene, uint64_t* counters, int render_type, uint8_t* rgba8,
+             uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t spp, void* stream)
+{
+    return trace_common(as, scene, counters, render_type, rgba8, w, h, y0, y1, spp, 0, 0, 1, stream);
+}
+
+int rt_trace_strips(const rt_accel* as, const rt_scene* scene, uint64_t* counters, int render_type, uint8_t* rgba8_compact,
+                    uint32_t w, uint32_t h, uint32_t strip_rows, uint32_t first_strip, uint32_t strip_stride,
+                    uint32_t spp, void* stream)
+{
+    if (strip_rows == 0 || (strip_rows & 7u) || strip_stride == 0) return RT_ERR_INVALID_ARGUMENT;
+    return trace_common(as, scene, counters, render_type, rgba8_compact, w, h, 0, h, spp, strip_rows, first_strip,
+                        strip_stride, stream);
 }
 
 const char* rt_error_string(int code)
@@ -204,8 +227,9 @@ const char* rt_error_string(int code)
     switch (code) {
     case RT_OK: return "ok";
     case RT_ERR_INVALID_ARGUMENT: return "invalid argument";
-    case RT_ERR_UNSUPPORTED: return "unsupported option (spatial splits)";
+    case RT_ERR_UNSUPPORTED: return "unsupported option";
     case RT_ERR_TOO_LARGE: return "too many triangles for the 29-bit node index";
+    case RT_ERR_BUILD_INCOMPLETE: return "SAH build incomplete (error flags in the scratch status word)";
     default: break;
     }
     if (code <= RT_ERR_HIP_BASE) return hipGetErrorString(static_cast<hipError_t>(RT_ERR_HIP_BASE - code));

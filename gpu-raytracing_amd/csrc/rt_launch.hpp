@@ -5,9 +5,30 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "rt_abi.h"
 
 namespace rt {
+
+// hipFuncSetAttribute is a per-DEVICE setting: run `fn` the first time a launch is made on each device of the process
+// (a single-process multi-GPU caller, main.cu's ncclCommInitAll shape, builds on every device).  `fn` is idempotent,
+// so two threads racing on the same device only repeat it.
+constexpr int kMaxDevices = 64;
+struct PerDeviceOnce {
+    std::atomic<unsigned char> done[kMaxDevices] = {};
+    template <class F> hipError_t operator()(F fn)
+    {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev < 0 || dev >= kMaxDevices) return fn();
+        if (done[dev].load(std::memory_order_acquire)) return hipSuccess;
+        e = fn();
+        if (e == hipSuccess) done[dev].store(1, std::memory_order_release);
+        return e;
+    }
+};
 
 // ---- radix sort geometry (radix_sort.hip)
 constexpr uint32_t kSortThreads = 256;
@@ -98,9 +119,10 @@ hipError_t launch_radix_pass(const uint32_t* keys_in, const uint32_t* vals_in, u
 // --pairs leaf slots: merge flag per candidate (2k, 2k+1), per-workgroup slot offsets, *num_leaves = L
 hipError_t launch_pair_slots(const rt_triangle* tris, uint32_t n, uint8_t* flags, uint32_t* block_sums,
                              uint32_t* num_leaves, hipStream_t st);
-// RunSahBuild (no splits).  Synchronises the stream (data-dependent number of levels).
+// RunSahBuild.  Synchronises the stream (data-dependent number of levels).  *status0 (may be null) = the build's error
+// flags as read back with the live-task counter: non-zero means the tree is incomplete.
 hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, bool splits, rt_triangle_pair* leaves,
-                            rt_node* nodes, void* scratch, hipStream_t st, uint32_t* levels_run);
+                            rt_node* nodes, void* scratch, hipStream_t st, uint32_t* levels_run, uint32_t* status0 = nullptr);
 // in-place exclusive scan of per-workgroup sums (one workgroup); *total = their sum
 hipError_t launch_block_scan(uint32_t* sums, uint32_t count, uint32_t* total, hipStream_t st);
 
@@ -114,6 +136,7 @@ struct TraceLaunch {
     int render_type;
     uint8_t* rgba8;
     uint32_t w, h, y0, y1, spp;
+    uint32_t strip_rows = 0, strip_first = 0, strip_stride = 1;   // strip_rows > 0: interleaved strips, compact output
 };
 hipError_t launch_trace(const TraceLaunch& t, hipStream_t st);
 

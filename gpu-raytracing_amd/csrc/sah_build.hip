@@ -1291,8 +1291,9 @@ SahLayout sah_layout(uint32_t n)
 }
 
 hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, bool splits, rt_triangle_pair* leaves,
-                            rt_node* nodes, void* scratch, hipStream_t st, uint32_t* levels_run)
+                            rt_node* nodes, void* scratch, hipStream_t st, uint32_t* levels_run, uint32_t* status0)
 {
+    if (status0) *status0 = 0;
     const SahLayout L = sah_layout(n);
     char* s = static_cast<char*>(scratch);
     SahArgs a;
@@ -1382,17 +1383,22 @@ hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, boo
             sah_split_kernel<<<split_blocks, kSplitWaves * 64, 0, st>>>(a, lvl);
             sah_partition_kernel<<<chunks, 256, 0, st>>>(a, lvl);
         }
-        uint32_t live = 0;
+        uint32_t live = 0, hdr[9] = {0};   // status[0..7] and small_count are adjacent in SahHeader
+        static_assert(offsetof(SahHeader, small_count) == offsetof(SahHeader, status) + 32, "one copy reads both");
         e = hipMemcpyAsync(&live, &a.H->level_count[lvl], 4, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(&nsmall, &a.H->small_count, 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(hdr, &a.H->status[0], sizeof hdr, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) return e;
+        nsmall = hdr[8];
+        if (status0) *status0 = hdr[0];
+        if (hdr[0] != 0) return hipSuccess;          // a kernel flagged an incomplete build (kSahErrLocals): stop here
         if (live == 0) break;
         if (lvl + 1 >= kSahMaxLevels) {
-            const uint32_t flag = kSahErrLevels;
+            const uint32_t flag = hdr[0] | kSahErrLevels;
+            if (status0) *status0 = flag;
             (void)hipMemcpyAsync(&a.H->status[0], &flag, 4, hipMemcpyHostToDevice, st);
             (void)hipStreamSynchronize(st);
-            break;
+            return hipSuccess;
         }
         batch = 4;
     }

@@ -43,9 +43,14 @@ constexpr int kTraceWaves = 4;
 #ifndef RT_TRACE_MIN_WAVES
 #define RT_TRACE_MIN_WAVES 7   // waves per SIMD the register allocator must fit (72 VGPRs: no spills; 8 -> 64 VGPRs spills)
 #endif
-constexpr int kRenderDebugBoxCount = 100;  // internal tuning aid (not in the ABI enum): pixel = raw u32 box-test count
-// the wave runs a box step while  stepping * park_den >= parked * park_num  (else one leaf phase);
-// defaults below, RT_TRACE_PARK="num,den" overrides them at run time (tuning knob).
+// Tuning build only (make TUNING=1 -> -DRT_TRACE_TUNING; never in the shipped library): render type 100 writes the raw
+// u32 box-test count per pixel (tools/divergence_stats.py) and RT_TRACE_PARK="num,den" overrides the park threshold.
+#ifdef RT_TRACE_TUNING
+constexpr int kRenderDebugBoxCount = 100;
+#else
+constexpr int kRenderDebugBoxCount = -1;   // matches no render type: every use below folds away
+#endif
+// the wave runs a box step while  stepping * park_den >= parked * park_num  (else one leaf phase)
 constexpr int kParkNum = 8, kParkDen = 1;
 
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
@@ -58,11 +63,14 @@ struct TraceParams {
     const rt_texture* textures;
     const rt_camera* camera;
     float light[3];
-    uint32_t root, count, num_materials;
+    uint32_t root, count, num_materials, num_textures;
     uint8_t* rgba8;
     uint32_t w, h, y0, y1, spp;
     unsigned long long* counters;
     uint32_t tiles_x, num_tiles;
+    // interleaved strips (rt_trace_strips): strip_tiles > 0 tile rows per strip; tile row t of the launch is row
+    // (t % strip_tiles) of strip  strip_first + (t / strip_tiles) * strip_stride  and is stored at tile row t (compactly)
+    uint32_t strip_tiles, strip_first, strip_stride;
     int park_num, park_den;
 };
 
@@ -492,7 +500,13 @@ __device__ __forceinline__ void shade_sample(const TraceParams& p, const rt_came
         const int i1 = rot == 1 ? 0 : (rot == 2 ? 2 : 1);
         const int i2 = rot == 1 ? 1 : (rot == 2 ? 0 : 2);
         material_id = at->material_id;
-        mat = p.materials[material_id];
+        // indices from scene data are range-checked (the reference is not: FileIO.cpp:191 gives faces before the first
+        // usemtl material_id -1): an id outside the table shades as material 0, a texture index outside the texture
+        // table reads as -1 (untextured)
+        mat = p.materials[(uint32_t)material_id < p.num_materials ? (uint32_t)material_id : 0u];
+        if ((uint32_t)mat.texture >= p.num_textures) mat.texture = -1;
+        if ((uint32_t)mat.bump >= p.num_textures) mat.bump = -1;
+        if ((uint32_t)mat.disp >= p.num_textures) mat.disp = -1;
         const rt_float3 n0 = at->normal[i0], n1 = at->normal[i1], n2 = at->normal[i2];
         s.n[0] = v3(n0.x, n0.y, n0.z); s.n[1] = v3(n1.x, n1.y, n1.z); s.n[2] = v3(n2.x, n2.y, n2.z);
         if (render_uses_surface(RENDER)) {
@@ -616,7 +630,13 @@ void trace_kernel(TraceParams p)
     const uint32_t lx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4);
     const uint32_t ly = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
     const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
-    const uint32_t x = tx * 8 + lx, y = p.y0 + ty * 8 + ly;
+    const uint32_t x = tx * 8 + lx;
+    uint32_t y = p.y0 + ty * 8 + ly, out_y = y;      // row band: rendered in place
+    if (p.strip_tiles) {                            // interleaved strips: rendered compactly
+        const uint32_t strip = p.strip_first + (ty / p.strip_tiles) * p.strip_stride;
+        y = (strip * p.strip_tiles + ty % p.strip_tiles) * 8 + ly;
+        out_y = ty * 8 + ly;
+    }
     const bool active = tile < p.num_tiles && x < p.w && y < p.y1;
 
     const rt_camera cam = *p.camera;
@@ -631,8 +651,9 @@ void trace_kernel(TraceParams p)
         shade_sample<RENDER>(p, cam, x, y, 0.5f, 0.5f, t, active, box_acc, tri_acc, steps, R, G, B, A);
     } else {
         float ar = 0, ag = 0, ab = 0, aa = 0;
+        const uint32_t side = p.spp == 4 ? 2u : 4u;   // stratified side x side sub-pixel grid (2 x 2 or 4 x 4)
         for (uint32_t s = 0; s < p.spp; s++) {
-            const float ox = ((float)(s % 4) + 0.5f) / 4.0f, oy = ((float)((s / 4) % 4) + 0.5f) / 4.0f;
+            const float ox = ((float)(s % side) + 0.5f) / (float)side, oy = ((float)((s / side) % side) + 0.5f) / (float)side;
             shade_sample<RENDER>(p, cam, x, y, ox, oy, t, active, box_acc, tri_acc, steps, R, G, B, A);
             ar += R; ag += G; ab += B; aa += A;
         }
@@ -641,7 +662,7 @@ void trace_kernel(TraceParams p)
     if (active) {
         uint32_t px = sat_u8(R) | (sat_u8(G) << 8) | (sat_u8(B) << 16) | (sat_u8(A) << 24);
         if (RENDER == kRenderDebugBoxCount) px = __float_as_uint(R);
-        reinterpret_cast<uint32_t*>(p.rgba8)[(size_t)y * p.w + x] = px;
+        reinterpret_cast<uint32_t*>(p.rgba8)[(size_t)out_y * p.w + x] = px;
     }
     if (p.counters) {
         const uint32_t bsum = wave_sum_u32(box_acc), tsum = wave_sum_u32(tri_acc);  // <= 64 * 2^26: no overflow per wave
@@ -668,12 +689,24 @@ hipError_t launch_trace(const TraceLaunch& t, hipStream_t st)
     p.root = t.as.root;
     p.count = t.as.count;
     p.num_materials = t.scene.num_materials;
+    p.num_textures = t.scene.textures ? t.scene.num_textures : 0;
     p.rgba8 = t.rgba8;
     p.w = t.w; p.h = t.h; p.y0 = t.y0; p.y1 = t.y1; p.spp = t.spp;
     p.counters = reinterpret_cast<unsigned long long*>(t.counters);
     p.tiles_x = (t.w + 7) / 8;
-    const uint32_t tiles_y = (t.y1 - t.y0 + 7) / 8;
+    uint32_t tiles_y = (t.y1 - t.y0 + 7) / 8;
+    p.strip_tiles = t.strip_rows / 8;
+    p.strip_first = t.strip_first;
+    p.strip_stride = t.strip_stride;
+    if (p.strip_tiles) {   // this launch's strips: first, first + stride, ... < ceil(h / strip_rows)
+        const uint32_t nstrips = (t.h + t.strip_rows - 1) / t.strip_rows;
+        if (t.strip_first >= nstrips) return hipSuccess;
+        tiles_y = ((nstrips - t.strip_first + t.strip_stride - 1) / t.strip_stride) * p.strip_tiles;
+    }
     p.num_tiles = p.tiles_x * tiles_y;
+    p.park_num = kParkNum;
+    p.park_den = kParkDen;
+#ifdef RT_TRACE_TUNING
     static const int* park = [] {
         static int v[2] = {kParkNum, kParkDen};
         if (const char* e = getenv("RT_TRACE_PARK")) {
@@ -684,6 +717,7 @@ hipError_t launch_trace(const TraceLaunch& t, hipStream_t st)
     }();
     p.park_num = park[0];
     p.park_den = park[1];
+#endif
     const uint32_t blocks = (p.num_tiles + kTraceWaves - 1) / kTraceWaves;
     const dim3 grid(blocks), block(kTraceWaves * 64);
     switch (t.render_type) {
@@ -696,7 +730,9 @@ hipError_t launch_trace(const TraceLaunch& t, hipStream_t st)
     case RT_RENDER_TEXTURE: trace_kernel<RT_RENDER_TEXTURE><<<grid, block, 0, st>>>(p); break;
     case RT_RENDER_TEXTURE_LIT: trace_kernel<RT_RENDER_TEXTURE_LIT><<<grid, block, 0, st>>>(p); break;
     case RT_RENDER_TEXTURE_LIT_SHADOWS: trace_kernel<RT_RENDER_TEXTURE_LIT_SHADOWS><<<grid, block, 0, st>>>(p); break;
+#ifdef RT_TRACE_TUNING
     case kRenderDebugBoxCount: trace_kernel<kRenderDebugBoxCount><<<grid, block, 0, st>>>(p); break;
+#endif
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

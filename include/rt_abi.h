@@ -112,6 +112,7 @@ enum {
     RT_ERR_INVALID_ARGUMENT = -1,
     RT_ERR_UNSUPPORTED = -2,       /* (no option of the built paths returns it any more; kept for ABI stability) */
     RT_ERR_TOO_LARGE = -3,         /* n exceeds the 29-bit child index of Node (Common.cuh:152-159) */
+    RT_ERR_BUILD_INCOMPLETE = -4,  /* rt_run_sah_build: a kernel flagged the tree incomplete (status word, see rt_sah_scratch_layout) */
     RT_ERR_HIP_BASE = -1000        /* -(hipError_t) + RT_ERR_HIP_BASE */
 };
 
@@ -189,9 +190,19 @@ int rt_radix_sort_u32_pairs(uint32_t* keys, uint32_t* values, uint32_t* tmp_keys
  * rgba8: full-frame linear RGBA8 buffer, pitch 4*w, row 0 first (= the surface contents, SURVEY A).
  * counters: optional device uint64[4], [0] += sum of box tests, [1] += sum of triangle tests (the reference's
  * num_tests is [0], Tracer.cu:503); [2] / [3] += wave-level box-phase / leaf-phase steps (profiling aid).  spp = 1 is the reference; spp in {4,16} is the
- * SURVEY 8(d) config-5 extension (4x4 stratified offsets, averaged before the u8 truncation). */
+ * SURVEY 8(d) config-5 extension (2x2 / 4x4 stratified sub-pixel offsets, averaged before the u8 truncation). */
 int rt_trace(const rt_accel* as, const rt_scene* scene, uint64_t* counters, int render_type, uint8_t* rgba8,
              uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t spp, void* stream);
+
+/* Multi-GPU partition into INTERLEAVED STRIPS (no reference counterpart: the reference traces on one GPU,
+ * main.cu:169).  A strip = strip_rows rows (a multiple of 8); this call renders strips first_strip, first_strip +
+ * strip_stride, ... of the w x h frame in ONE launch and stores them COMPACTLY: its j-th strip occupies rows
+ * [j*strip_rows, (j+1)*strip_rows) of rgba8_compact (pitch 4*w), which must hold
+ * ceil(ceil(h / strip_rows) / strip_stride) strips.  Rank r of P calls it with (first_strip, strip_stride) = (r, P);
+ * rank 0 gathers the compact buffers and de-interleaves them (gpu-raytracing_amd/sharding.py). */
+int rt_trace_strips(const rt_accel* as, const rt_scene* scene, uint64_t* counters, int render_type,
+                    uint8_t* rgba8_compact, uint32_t w, uint32_t h, uint32_t strip_rows, uint32_t first_strip,
+                    uint32_t strip_stride, uint32_t spp, void* stream);
 
 /* static string for a return code */
 const char* rt_error_string(int code);

@@ -1494,7 +1494,14 @@ static ora_f3 shade_pixel(const ora_triangle_pair* leaves, const ora_node* nodes
     int second_tri = rr.tri_id & 1;
     const ora_triangle_pair* pair = &leaves[rr.tri_id >> 1];
     ora_attributes at = rotate_attributes(&attributes[rr.primitive_id], second_tri, pair->rot_x, pair->rot_y);
-    const ora_material* mat = &materials[at.material_id];
+    /* indices from scene data are range-checked (the reference reads out of bounds, e.g. material_id -1 for faces before
+     * the first usemtl, FileIO.cpp:191): a material id outside [0, num_materials) shades as material 0, a texture index
+     * outside the texture table reads as -1 (untextured).  Same rule in trace_kernel.hip. */
+    ora_material mat_checked = materials[(uint32_t)at.material_id < num_materials ? (uint32_t)at.material_id : 0u];
+    if ((uint32_t)mat_checked.texture >= g_num_textures) mat_checked.texture = -1;
+    if ((uint32_t)mat_checked.bump >= g_num_textures) mat_checked.bump = -1;
+    if ((uint32_t)mat_checked.disp >= g_num_textures) mat_checked.disp = -1;
+    const ora_material* mat = &mat_checked;
     const accel_t as = {leaves, nodes, root, count};
     const float spread = 2.0f / w;
     ora_f3 tri[3];
@@ -1551,8 +1558,11 @@ int ora_trace(const ora_triangle_pair* leaves, const ora_node* nodes, uint32_t r
             } else {
                 ora_f3 acc = f3(0, 0, 0);
                 float aacc = 0.0f;
+                /* stratified side x side sub-pixel grid: 2 x 2 for 4 spp, 4 x 4 for 16 spp (the spp extension is this
+                 * build's, for BASELINE config 5; the reference traces one centred sample) */
+                const uint32_t side = spp == 4 ? 2u : 4u;
                 for (uint32_t s = 0; s < spp; s++) {
-                    float ox = ((float)(s % 4) + 0.5f) / 4.0f, oy = ((float)((s / 4) % 4) + 0.5f) / 4.0f, a1;
+                    float ox = ((float)(s % side) + 0.5f) / (float)side, oy = ((float)((s / side) % side) + 0.5f) / (float)side, a1;
                     acc = add3(acc, shade_pixel(leaves, nodes, root, count, attributes, materials, num_materials,
                                                 camera, light, render_type, x, y, w, h, ox, oy, &st, &a1));
                     aacc += a1;

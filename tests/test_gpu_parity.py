@@ -207,11 +207,42 @@ def test_full_size_1m_properties(rt, scenes, ora):
     o = ora.build_bvh(tris)
     assert_nodes_equal(g["nodes"], o["nodes"], "1M grid")
     assert g["leaves"].tobytes() == o["leaves"].tobytes()
-    cam = scenes.camera_b(G)
-    gi, gc = gpu_trace(g, cam, 1920, 1080, 0)
-    oi, oc = ora.trace(o["leaves"], o["nodes"], 0, 2, cam, 1920, 1080, render_type=0)
-    assert (gc == oc[:2]).all(), f"{gc} vs {oc}"
-    assert (gi == oi).all()
+    # both cameras at the full 1920x1080: camera A ("top-down") is bench.py's headline frame (448 box tests per ray),
+    # camera B ("oblique") the short-traversal one; whole frame byte-exact and sum(box) / sum(tri) identical
+    for cam in (scenes.camera_a(G), scenes.camera_b(G)):
+        gi, gc = gpu_trace(g, cam, 1920, 1080, 0)
+        oi, oc = ora.trace(o["leaves"], o["nodes"], 0, 2, cam, 1920, 1080, render_type=0)
+        assert (gc == oc[:2]).all(), f"{gc} vs {oc}"
+        assert (gi == oi).all()
+    assert int(gc[0]) > 0
+
+
+def test_full_size_config5_4k_16spp(rt, scenes, ora):
+    """BASELINE config 5 at full size: the 1M-triangle mesh, 3840x2160, 16 spp (camera A).  The GPU renders the whole
+    frame (132.7 M rays); the oracle renders two bands of 32 full rows (3.9 M rays); those rows must be byte-exact, the
+    bands' sum(box) / sum(tri) identical to a GPU launch restricted to the same rows, and the band launches of a
+    4-way split must add up to the full frame's counters (what a multi-GPU run relies on)."""
+    import torch
+    from helpers import gpu_build, gpu_trace
+    G, W, H, SPP = 708, 3840, 2160, 16
+    tris = scenes.grid_mesh(G, 1)
+    g = gpu_build(tris)
+    o = ora.build_bvh(tris)
+    assert g["nodes"].tobytes() == o["nodes"].tobytes()
+    cam = scenes.camera_a(G)
+    full, fc = gpu_trace(g, cam, W, H, 0, spp=SPP)
+    assert int((full[..., 0] > 0).sum()) > W * H // 2
+    for r0 in (256, 1064):
+        r1 = r0 + 32
+        oi, oc = ora.trace(o["leaves"], o["nodes"], 0, 2, cam, W, H, render_type=0, spp=SPP, rows=(r0, r1))
+        assert (full[r0:r1] == oi[r0:r1]).all(), f"rows [{r0}, {r1}) differ from the oracle"
+        _, bc = gpu_trace(g, cam, W, H, 0, spp=SPP, rows=(r0, r1))
+        assert (bc == oc[:2]).all(), f"band counters {bc} vs oracle {oc}"
+    total = np.zeros(2, np.uint64)
+    for k in range(4):
+        _, bc = gpu_trace(g, cam, W, H, 0, spp=SPP, rows=(k * H // 4, (k + 1) * H // 4))
+        total += bc
+    assert (total == fc).all(), f"band sums {total} vs full frame {fc}"
 
 
 def test_build_and_trace_capture_in_a_hip_graph(rt, scenes, ora):

@@ -46,26 +46,33 @@ __global__ __launch_bounds__(256) void walk(const uint4* __restrict__ pairs, uin
 
 int main()
 {
-    const uint32_t npairs = 16384;          // 1 MB window
-    std::vector<uint32_t> host((size_t)npairs * 16);
+    // windows: 16 KiB (fits every CU's 32 KiB L1: the tracer's 97 % L1-hit regime), 1 MiB (L2), 64 MiB (Infinity Cache)
+    const uint32_t max_pairs = 1u << 20;   // 64 MiB
+    std::vector<uint32_t> host((size_t)max_pairs * 16);
     for (size_t i = 0; i < host.size(); i++) host[i] = (uint32_t)(i * 2654435761u);
     uint4* dev; uint32_t* sink;
     hipMalloc(&dev, host.size() * 4); hipMalloc(&sink, 4);
     hipMemcpy(dev, host.data(), host.size() * 4, hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const uint32_t blocks = 256 * 8, iters = 2000;     // 8 workgroups x 4 waves = 32 waves per CU
-    for (uint32_t share : {1u, 2u, 4u, 8u, 64u})
-        for (int mode = 0; mode < 2; mode++) {
-            for (int rep = 0; rep < 2; rep++) {
-                hipEventRecord(e0);
-                if (mode == 0) walk<0><<<blocks, 256>>>(dev, npairs, share, iters, sink);
-                else walk<1><<<blocks, 256>>>(dev, npairs, share, iters, sink);
-                hipEventRecord(e1); hipEventSynchronize(e1);
+    printf("# ta_microbench: wave-wide 16-byte-per-lane loads, 4 per iteration (one 64-byte pair per lane), 32 waves per CU,\n"
+           "# dependent chain (next address from loaded data).  cycles/iter/CU = kernel time x 2.4 GHz / (wave-iterations per CU);\n"
+           "# one iteration = 4 wave-loads, so cycles per wave-load = that / 4 and cycles per distinct lane address = that / 4 / (64 / share).\n");
+    for (uint32_t npairs : {256u, 16384u, max_pairs})
+        for (uint32_t share : {1u, 2u, 4u, 8u, 16u, 64u})
+            for (int mode = 0; mode < 2; mode++) {
+                for (int rep = 0; rep < 2; rep++) {
+                    hipEventRecord(e0);
+                    if (mode == 0) walk<0><<<blocks, 256>>>(dev, npairs, share, iters, sink);
+                    else walk<1><<<blocks, 256>>>(dev, npairs, share, iters, sink);
+                    hipEventRecord(e1); hipEventSynchronize(e1);
+                }
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                const double wave_iters = (double)blocks * 4 * iters;
+                const double cyc = ms * 1e-3 * 2.4e9 / (wave_iters / 256);
+                printf("window %6u KiB  share %2u lanes/pair (%2u distinct)  mode %d (%s): %8.3f ms  %6.1f cycles/iter/CU  %5.1f cycles/wave-load  %5.2f cycles/distinct address\n",
+                       npairs * 64 / 1024, share, 64 / share, mode, mode ? "quad fetch " : "own pair x4", ms, cyc, cyc / 4,
+                       cyc / 4 / (64.0 / share));
             }
-            float ms; hipEventElapsedTime(&ms, e0, e1);
-            const double wave_iters = (double)blocks * 4 * iters;
-            printf("share %2u lanes/pair  mode %d (%s): %.3f ms  %.1f ns per wave-iteration per CU-slot, %.1f cycles/iter/CU at 2.4 GHz\n",
-                   share, mode, mode ? "quad fetch" : "own pair x4", ms, ms * 1e6 / wave_iters, ms * 1e-3 * 2.4e9 / (wave_iters / 256));
-        }
     return 0;
 }
