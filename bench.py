@@ -37,6 +37,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
 L1_PEAK_GBS = 256 * 64 * 2.4     # vector L1 (TCP) data path: 256 CUs x 64 B/clk x 2.4 GHz = 39,321.6 GB/s
+# measured ceiling of DIVERGENT 16-byte-per-lane gathers through the same path (profiles/r02_ta_microbench.txt): one
+# lane request per 0.69 cycles unless the four lanes of a quad agree -> 16 B / 0.69 clk x 256 CUs x 2.4 GHz
+GATHER_CEILING_GBS = 256 * 16 / 0.69 * 2.4
 
 
 def parse():
@@ -448,6 +451,11 @@ def main():
             "kernel_ms": round(serial_ms, 4),
             "kernel_ms_is": f"median of 22 serial launches of this rank's part, HIP events on the launch stream "
                             f"(trace_kernel<{iso_rt}>: same rays and tests as the timed region's trace_kernel<{args.render_type}>)",
+            "divergent_gather_ceiling": {"peak": round(GATHER_CEILING_GBS, 1), "unit": "GB/s",
+                                         "frac": round(serial_l1 / GATHER_CEILING_GBS, 4),
+                                         "is": "16-byte-per-lane loads whose quads disagree cost 0.69 cycles per lane (measured, "
+                                               "profiles/r02_ta_microbench.txt); lanes of a quad that visit the same node share one "
+                                               "request, which is how achieved can approach or pass this line"},
             "algorithmic_over_hbm_peak": round(serial_l1 / HBM_PEAK_GBS, 4),
             "algorithmic_over_hbm_peak_is": "> 1 means cache reuse: these bytes cannot all have come from HBM",
             "traffic": traffic, "traffic_source": traffic_src,

@@ -1,8 +1,22 @@
-// main.cpp -- headless counterpart of the reference's main.cu: what Display() does at frame 0 (main.cu:215-265)
-// plus one Trace() (main.cu:125-192), with the frame written as a PPM instead of shown in a GL window.
+// main.cpp -- headless counterpart of the reference's main.cu: the Display() frame loop (main.cu:215-292) -- update the
+// camera from the input state, build at frame 0, Trace() (main.cu:125-192), present -- with the frame written as a PPM
+// instead of shown in a GL window and the GLUT callbacks (Keyboard / Motion / MouseWheel, main.cu:294-392) replaced by
+// a scripted input path.
 //
 //   rt_cli <file.obj> [--type sah|bottom-up|hybrid] [--pairs] [--splits] [--render depth|boxtests|tritests|material|lods|diffuse|texture|texturelit|shadows]
 //          [--width W] [--height H] [--spp N] [--yaw Y --pitch P --pos X Y Z] [--out frame.ppm] [--frames K]
+//          [--path "<ev>,<ev>,..."] [--rebuild]
+//
+// --path: one comma-separated entry per frame (repeated cyclically when shorter than --frames); an entry is a
+// concatenation of events applied BEFORE that frame is traced, in the order the GLUT callbacks would have run:
+//     w a s d q e _   keys held during the frame (`_` = space)      -> InputState -> UpdateCameraPosition (main.cu:219)
+//     l<dx>:<dy>      a mouse drag of (dx, dy) pixels               -> UpdateCameraLookDelta + UpdateCamera (Motion)
+//     zi / zo         one mouse-wheel step in / out                 -> UpdateCameraZoom (MouseWheel)
+//     m               next render type                              -> Keyboard 'm' (main.cu:326-329)
+//     -               nothing
+// With --frames K > 1 and --out f.ppm the frames go to f_0000.ppm, f_0001.ppm, ...; every frame prints its
+// TraceRays time, sum of box tests and Mrays/s (the reference prints the first frame's, main.cu:180-183).
+// --rebuild: the bottom-up build is re-run every frame (dynamic-scene loop; asynchronous, nothing is read back).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -42,7 +56,8 @@ int main(int argc, char** argv)
     Arguments args = ParseCmd(argc, argv);
     int width = 1024, height = 768, frames = 1;                 // the reference's window size (main.cu:44-45)
     unsigned spp = 1;
-    std::string out;
+    std::string out, path;
+    bool rebuild = false;
     bool have_pos = false, have_yaw = false, have_pitch = false;
     vec3 pos{0, 0, 0};
     float yaw = 0, pitch = 0;
@@ -55,6 +70,8 @@ int main(int argc, char** argv)
         else if (a == "--spp") { spp = (unsigned)atoi(next(1)); i++; }
         else if (a == "--frames") { frames = atoi(next(1)); i++; }
         else if (a == "--out") { out = next(1); i++; }
+        else if (a == "--path") { path = next(1); i++; }
+        else if (a == "--rebuild") { rebuild = true; }
         else if (a == "--yaw") { yaw = (float)atof(next(1)); have_yaw = true; i++; }
         else if (a == "--pitch") { pitch = (float)atof(next(1)); have_pitch = true; i++; }
         else if (a == "--pos") { pos = make_vec3((float)atof(next(1)), (float)atof(next(2)), (float)atof(next(3))); have_pos = true; i += 3; }
@@ -95,11 +112,17 @@ int main(int argc, char** argv)
     printf("%s time elapsed: %fms\n", sah ? "RunSahBuild" : "RunBottomUpBuild", build_ms);
     // number of leaves L: n, unless --pairs merged triangles.  The reference roots a hybrid tree at 2n+1 even then
     // (main.cu:222); the top tree is written at 2L, so the root is 2L+1.
-    size_t num_leaves_off;
-    if (sah) { rt_sah_scratch_layout lay; rt_sah_scratch_layout_get(n, &lay); num_leaves_off = lay.num_leaves; }
-    else { rt_bu_scratch_layout lay; rt_bu_scratch_layout_get(n, &lay); num_leaves_off = lay.num_leaves; }
-    unsigned num_leaves = n;
+    size_t num_leaves_off, status_off;
+    if (sah) { rt_sah_scratch_layout lay; rt_sah_scratch_layout_get(n, &lay); num_leaves_off = lay.num_leaves; status_off = lay.status; }
+    else { rt_bu_scratch_layout lay; rt_bu_scratch_layout_get(n, &lay); num_leaves_off = lay.num_leaves; status_off = lay.status; }
+    unsigned num_leaves = n, build_status = 0;
     check(hipMemcpy(&num_leaves, static_cast<char*>(in.scratch) + num_leaves_off, 4, hipMemcpyDeviceToHost));
+    // the builders' error flags (status word of the scratch layout): a non-zero value means an incomplete tree
+    check(hipMemcpy(&build_status, static_cast<char*>(in.scratch) + status_off, 4, hipMemcpyDeviceToHost));
+    if (build_status != 0) {
+        fprintf(stderr, "gpu_assert: %s reported error flags 0x%x (incomplete tree)\n", sah ? "RunSahBuild" : "RunBottomUpBuild", build_status);
+        return 3;
+    }
     const unsigned root_index = hybrid ? (num_leaves * 2 > 2 ? num_leaves * 2 : 2) + 1 : 0;
     if (args.enable_pairs) printf("  leaves after pairing: %u of %u triangles\n", num_leaves, n);
 
@@ -137,28 +160,87 @@ int main(int argc, char** argv)
     MemoryBuffer<uint64_t> num_tests(4);
     for (int k = 0; k < 4; k++) num_tests[k] = 0;
     num_tests.toDevice();
+    // the scripted input path: entry f % size is applied before frame f
+    std::vector<std::string> events;
+    for (size_t b = 0; b <= path.size() && !path.empty();) {
+        const size_t e = path.find(',', b);
+        events.push_back(path.substr(b, e == std::string::npos ? std::string::npos : e - b));
+        if (e == std::string::npos) break;
+        b = e + 1;
+    }
+    auto write_ppm = [&](const std::string& name) {
+        frame.toHost();
+        std::ofstream os(name, std::ios::binary);
+        os << "P6\n" << width << " " << height << "\n255\n";
+        for (size_t p = 0; p < (size_t)width * height; p++) os.write(reinterpret_cast<const char*>(&frame[p * 4]), 3);
+        printf("wrote %s\n", name.c_str());
+    };
     float trace_ms = 0;
+    double total_ms = 0;
     for (int f = 0; f < frames; f++) {
+        // ---- input callbacks of this frame, then Display(): UpdateCameraPosition(camera, input) (main.cu:219)
+        InputState input;
+        if (!events.empty()) {
+            const std::string& ev = events[(size_t)f % events.size()];
+            for (size_t c = 0; c < ev.size(); c++) {
+                switch (ev[c]) {
+                case 'w': input.key_pressed_w = true; break;
+                case 'a': input.key_pressed_a = true; break;
+                case 's': input.key_pressed_s = true; break;
+                case 'd': input.key_pressed_d = true; break;
+                case 'q': input.key_pressed_q = true; break;
+                case 'e': input.key_pressed_e = true; break;
+                case '_': input.key_pressed_space = true; break;
+                case 'm': args.render_type = RenderType((args.render_type + 1) % kCount); break;   // main.cu:326-329
+                case 'z':                                                                           // MouseWheel (main.cu:294-301)
+                    if (c + 1 < ev.size()) { UpdateCameraZoom(camera[0], ev[c + 1] == 'i' ? 1 : -1); c++; }
+                    break;
+                case 'l': {                                                                          // Motion (main.cu:376-392)
+                    char* endp = nullptr;
+                    const long dx = strtol(ev.c_str() + c + 1, &endp, 10);
+                    long dy = 0;
+                    if (endp && *endp == ':') dy = strtol(endp + 1, &endp, 10);
+                    UpdateCameraLookDelta(camera[0], (float)dx, (float)dy);
+                    UpdateCamera(camera[0]);
+                    c = (size_t)(endp - ev.c_str()) - 1;
+                    break;
+                }
+                default: break;
+                }
+            }
+        }
+        UpdateCameraPosition(camera[0], input);
+        camera.toDevice();                                                                           // Trace(): main.cu:151
+        if (rebuild && f > 0 && !sah) RunBottomUpBuild(in, args, hybrid);
+        for (int k = 0; k < 4; k++) num_tests[k] = 0;
+        num_tests.toDevice();
         check(hipEventRecord(e0, nullptr));
         Trace(in.triangles_out, in.nodes_out, frame.gpu(), width, height, camera.gpu(), root_index, root_count, args.render_type,
-              view, f == 0 ? num_tests.gpu() : nullptr, 0, (unsigned)height, spp);
+              view, num_tests.gpu(), 0, (unsigned)height, spp);
         check(hipEventRecord(e1, nullptr));
         check(hipEventSynchronize(e1));
         check(hipEventElapsedTime(&trace_ms, e0, e1));
+        total_ms += trace_ms;
+        num_tests.toHost();
         if (f == 0) {
             printf("TraceRays time elapsed: %fms\n", trace_ms);
-            num_tests.toHost();
             printf("TraceRays number of tests %llu\n", (unsigned long long)num_tests[0]);   // main.cu:180-183
         }
+        if (frames > 1) {
+            printf("frame %d: TraceRays %fms  box tests %llu  triangle tests %llu  %.1f Mrays/s  render %d  pos %.9g %.9g %.9g yaw %.9g pitch %.9g\n",
+                   f, trace_ms, (unsigned long long)num_tests[0], (unsigned long long)num_tests[1],
+                   (double)width * height * spp / trace_ms / 1e3, (int)args.render_type,
+                   camera[0].position.x, camera[0].position.y, camera[0].position.z, camera[0].yaw, camera[0].pitch);
+            if (!out.empty()) {
+                char suffix[32];
+                snprintf(suffix, sizeof suffix, "_%04d.ppm", f);
+                const size_t dot = out.rfind(".ppm");
+                write_ppm((dot == std::string::npos ? out : out.substr(0, dot)) + suffix);
+            }
+        }
     }
-    if (frames > 1) printf("last frame: %fms = %.1f Mrays/s\n", trace_ms, (double)width * height * spp / trace_ms / 1e3);
-    if (!out.empty()) {
-        frame.toHost();
-        std::ofstream os(out, std::ios::binary);
-        os << "P6\n" << width << " " << height << "\n255\n";
-        for (size_t p = 0; p < (size_t)width * height; p++) os.write(reinterpret_cast<const char*>(&frame[p * 4]), 3);
-        printf("wrote %s\n", out.c_str());
-    }
+    if (frames > 1) printf("%d frames: mean TraceRays %fms = %.1f fps (trace only)\n", frames, total_ms / frames, 1e3 * frames / total_ms);
+    else if (!out.empty()) write_ppm(out);
     (void)hipFree(in.triangles_in); (void)hipFree(in.triangles_out); (void)hipFree(in.scratch); (void)hipFree(in.nodes_out);
     if (d_attr) (void)hipFree(d_attr);
     if (d_mat) (void)hipFree(d_mat);

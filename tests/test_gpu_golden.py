@@ -141,3 +141,93 @@ def test_rt_cli_sah_pairs_splits(tmp_path, rt, ora):
     raw = open(out, "rb").read()
     got = np.frombuffer(raw[len(b"P6\n320 200\n255\n"):], np.uint8).reshape(200, 320, 3)
     assert (got == exp[..., :3]).all()
+
+
+def _replay_path(host, cam, events, frames):
+    """The camera of every frame of `rt_cli --path`: the same host library calls (librt_host.so, pinned byte for byte
+    against the compiled reference Camera.cu in test_host_mirror.py) in the order main.cpp / the GLUT callbacks apply them."""
+    import ctypes
+    H = ctypes.CDLL(os.path.join(ROOT, "gpu-raytracing_amd", "host", "librt_host.so"))
+    H.rth_camera_look.argtypes = [ctypes.c_void_p, ctypes.c_float, ctypes.c_float]
+    H.rth_camera_zoom.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    H.rth_camera_move.argtypes = [ctypes.c_void_p, ctypes.c_uint]
+    H.rth_update_camera.argtypes = [ctypes.c_void_p]
+    cam = np.ascontiguousarray(cam).copy()
+    p = cam.ctypes.data_as(ctypes.c_void_p)
+    bits = {"w": 1, "a": 2, "s": 4, "d": 8, "q": 16, "e": 32, "_": 64}
+    out, render_steps = [], 0
+    renders = []
+    for f in range(frames):
+        ev, keys, i = events[f % len(events)], 0, 0
+        while i < len(ev):
+            c = ev[i]
+            if c in bits:
+                keys |= bits[c]
+            elif c == "m":
+                render_steps += 1
+            elif c == "z":
+                H.rth_camera_zoom(p, 1 if ev[i + 1] == "i" else -1)
+                i += 1
+            elif c == "l":
+                m = re.match(r"l(-?\d+):(-?\d+)", ev[i:])
+                H.rth_camera_look(p, float(m.group(1)), float(m.group(2)))
+                H.rth_update_camera(p)
+                i += len(m.group(0)) - 1
+            i += 1
+        H.rth_camera_move(p, keys)
+        out.append(cam.copy())
+        renders.append(render_steps)
+    return out, renders
+
+
+def test_rt_cli_frame_loop_with_input_path(tmp_path, rt, ora):
+    """The reference's Display() loop (main.cu:215-292), headless: build at frame 0, then per frame the input callbacks,
+    UpdateCameraPosition, Trace, present.  8 frames over the cornell fixture driven by keys, mouse drags, the wheel and
+    the 'm' render-type key; every frame's PPM and printed sum of box tests against the oracle on the replayed camera."""
+    host = importlib.import_module("gpu-raytracing_amd.host_py")
+    cli = os.path.join(ROOT, "gpu-raytracing_amd", "host", "rt_cli")
+    obj = os.path.join(GOLD, "cornell34.obj")
+    out = str(tmp_path / "walk.ppm")
+    path = "-,w,wd,l25:-10,zi,m,a_l-40:5,zoe"
+    events, K, W, H = path.split(","), 8, 256, 160
+    p = subprocess.run([cli, obj, "--type", "bottom-up", "--render", "depth", "--width", str(W), "--height", str(H),
+                        "--pos", "5", "5", "-5.25", "--yaw", "0", "--pitch", "0", "--frames", str(K), "--path", path,
+                        "--out", out], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    s = host.LoadOBJFromFile(obj)
+    cam = host.InitialiseCamera(s["aabb"])
+    cam["position"], cam["yaw"], cam["pitch"] = [5, 5, -5.25], 0, 0
+    cam = host.UpdateCamera(cam)
+    cams, renders = _replay_path(host, cam, events, K)
+    o = ora.build_bvh(s["triangles"])
+    lines = re.findall(r"frame (\d+): TraceRays \S+ms  box tests (\d+)  triangle tests (\d+) .* render (\d+)  pos", p.stdout)
+    assert len(lines) == K
+    seen = set()
+    for f in range(K):
+        rtype = renders[f] % 9
+        assert int(lines[f][3]) == rtype
+        exp, cnt = ora.trace(o["leaves"], o["nodes"], 0, 2, cams[f], W, H, render_type=rtype, attributes=s["attributes"],
+                             materials=s["materials"], light=tuple(s["light"]))
+        assert (int(lines[f][1]), int(lines[f][2])) == (int(cnt[0]), int(cnt[1])), f"frame {f} test counts"
+        raw = open(str(tmp_path / f"walk_{f:04d}.ppm"), "rb").read()
+        hdr = f"P6\n{W} {H}\n255\n".encode()
+        got = np.frombuffer(raw[len(hdr):], np.uint8).reshape(H, W, 3)
+        assert (got == exp[..., :3]).all(), f"frame {f}"
+        seen.add(got.tobytes())
+    assert len(seen) >= 6, "the camera path changes the picture"
+    assert f"{K} frames: mean TraceRays" in p.stdout
+
+
+def test_rt_cli_rebuild_every_frame(tmp_path, rt, ora):
+    """--rebuild: the LBVH is rebuilt before every frame of the loop (asynchronous launches behind the trace of the
+    previous frame); pictures and counters must not change."""
+    host = importlib.import_module("gpu-raytracing_amd.host_py")
+    cli = os.path.join(ROOT, "gpu-raytracing_amd", "host", "rt_cli")
+    obj = os.path.join(GOLD, "tiles", "tiles.obj")
+    res = []
+    for extra in ([], ["--rebuild"]):
+        p = subprocess.run([cli, obj, "--type", "bottom-up", "--render", "boxtests", "--width", "192", "--height", "128",
+                            "--frames", "4", "--path", "w,l10:3"] + extra, capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, p.stderr
+        res.append(re.findall(r"frame (\d+): TraceRays \S+ms  box tests (\d+)  triangle tests (\d+)", p.stdout))
+    assert len(res[0]) == 4 and res[0] == res[1]
