@@ -20,16 +20,20 @@
 //     emits the parent's two Node slots (each 32-byte slot = box + descriptor of one child) and
 //     climbs on.  A workgroup owns 1024 consecutive leaves; sub-trees that cannot finish inside it
 //     (their sibling lies in another workgroup) are emitted as "open roots" -- at most 2 x depth <= 124
-//     per workgroup -- and the next, 16x smaller level treats those as its leaves.  4 launches build
-//     1M triangles; nothing is exchanged between workgroups inside a launch, so there is no
-//     inter-workgroup protocol, no global atomic and no spin.
+//     per workgroup, 10 on average on the bench mesh -- and the next level (64x fewer blocks) treats
+//     those as its leaves;
+//   * two launches build the whole hierarchy: the leaf level, then ALL upper levels: when a workgroup
+//     has written its block's open roots (write-through stores) it takes a ticket on the counter of
+//     the next level's block (one relaxed device atomic); the workgroup that takes the LAST ticket of a
+//     block acquires and processes that block, and so on up to the root.  Nobody waits for anybody:
+//     there is no spin and no dependence on dispatch order, a workgroup either continues upward or
+//     exits.  (Chaining the leaf level into the same launch was measured slower: the leaf pass then
+//     shares its register budget with the upper passes.)
 //
 // Node words: w28 = child:29|type:3 and the box of a slot are written by the workgroup that completes
 // the OWNING node; w12 = parent:29|count:3 of a pair is written by whoever completes the pair's parent
 // (it knows the parent slot; the counts travel with the segment as 2 bits).  Every dword of every
 // slot is written exactly once, so no write ordering between threads is needed.
-#include <mutex>
-
 #include "rt_device.hpp"
 #include "rt_launch.hpp"
 #include "rt_pairing.hpp"
@@ -38,6 +42,17 @@ namespace rt {
 
 constexpr uint32_t kLockEmpty = 0xFFFFFFFFu;
 constexpr uint32_t kLockDone = 0xFFFFFFFEu;
+constexpr uint32_t kCap = kUpperCap;  // segments an upper pass handles in LDS (the leaf pass: kLeafCap leaves)
+// open roots of 64 source blocks an upper block folds in ONE pass (else kSubFan at a time).  Real scenes give about 10
+// per block (2 x depth 62 = 124 is the bound), so the sub-pass path only runs in the test variant of the library that
+// the Makefile builds with a tiny value here (librt_amd_smallcap.so, tests/test_gpu_parity.py).
+#ifndef RT_LBVH_FAST_CAP
+#define RT_LBVH_FAST_CAP kCap
+#endif
+static_assert(RT_LBVH_FAST_CAP <= kCap, "one pass holds kCap segments");
+static_assert(kLeafCap <= kCap && kSubFan * kMaxOpen <= kCap && kUpperFan % kSubFan == 0 && kUpperFan / kSubFan * kMaxOpen <= kCap,
+              "the fallback's sub-passes and its merging pass always fit one pass");
+static_assert(kUpperFan == 64, "pref[] is filled by one wave and searched in 6 steps");
 
 struct LevelArgs {
     const float* tris;           // 9 floats per triangle
@@ -47,17 +62,22 @@ struct LevelArgs {
     const uint32_t* n_dev;
     rt_triangle_pair* leaves;
     rt_node* nodes;
-    const uint32_t* prev_cnt;    // upper levels: open-root counts of the previous level's workgroups
-    const uint32_t* prev_rec;    // upper levels: their records [blocks][kMaxOpen][kRecDwords]
-    uint32_t prev_blocks;
-    uint32_t* out_cnt;
-    uint32_t* out_rec;
     uint32_t* status;
+    // per level k: blocks[k] blocks; cnt[k][block] open roots, rec[k][block][kMaxOpen][kRecDwords] their records;
+    // arrive[k][block] (k >= 1) tickets taken by the level k-1 blocks that feed it (zero before the launch);
+    // sub_cnt / sub_rec [k][block][kUpperFan / kSubFan] scratch of the fallback path
+    uint32_t num_levels;
+    uint32_t blocks[kMaxLevels];
+    uint32_t* cnt[kMaxLevels];
+    uint32_t* rec[kMaxLevels];
+    uint32_t* arrive[kMaxLevels];
+    uint32_t* sub_cnt[kMaxLevels];
+    uint32_t* sub_rec[kMaxLevels];
 };
 
-template <bool LEAF>
-struct LevelCfg {
-    static constexpr uint32_t CAP = LEAF ? kLeafCap : kUpperCap;
+template <uint32_t CAP_>
+struct LevelCfgT {
+    static constexpr uint32_t CAP = CAP_;
     static constexpr uint32_t PER = (CAP + 1 + 1023) / 1024;  // boundaries per thread in the final compaction
     // LDS carve (dwords)
     static constexpr uint32_t oDl = 0;                 // int   [CAP+1]  delta at boundary b
@@ -67,10 +87,28 @@ struct LevelCfg {
     static constexpr uint32_t oDesc = oRange + CAP;
     static constexpr uint32_t oCc = oDesc + CAP;
     static constexpr uint32_t oBox = oCc + CAP;        // float [6][CAP]
-    static constexpr uint32_t oWs = oBox + 6 * CAP;    // scan workspace + prefix table
-    static constexpr uint32_t kDwords = oWs + 64;
+    static constexpr uint32_t oWs = oBox + 6 * CAP;    // scan workspace [0, 32), hand-off flag [32], prefix table [40, 40 + 65)
+    static constexpr uint32_t kDwords = oWs + 40 + kUpperFan + 8;
     static constexpr size_t kBytes = (size_t)kDwords * 4;
 };
+typedef LevelCfgT<kLeafCap> LeafCfg;    // 50 KB of LDS: two 1024-thread workgroups per CU at the leaf level
+typedef LevelCfgT<kCap> UpperCfg;       // 98 KB: the upper levels run a handful of workgroups
+
+// Hand-off stores: write-through at agent scope (`sc1`), so that the records a workgroup leaves for the next level are
+// in memory once its `s_waitcnt vmcnt(0)` returns -- without an L2 write-back per workgroup (an agent-scope release
+// fence = buffer_wbl2 flushes every dirty line of the XCD's L2, i.e. the leaves and nodes everybody is streaming out:
+// measured 2.3x on the 10M build).  MI355X_MICROARCH.md, inter-workgroup visibility: sc1 stores, drained, then the
+// ticket; the last arriver acquires before its workgroup reads.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_sc1(uint4* p, uint32_t x, uint32_t y, uint32_t z, uint32_t w)
+{
+    const u32x4 v = {x, y, z, w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_sc1(uint32_t* p, uint32_t v)
+{
+    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
 
 __device__ __forceinline__ int delta_adjacent(const uint32_t* __restrict__ codes, int g, uint32_t n)
 {
@@ -80,11 +118,14 @@ __device__ __forceinline__ int delta_adjacent(const uint32_t* __restrict__ codes
     return c0 == c1 ? 32 + __clz((uint32_t)g ^ (uint32_t)(g + 1)) : __clz(c0 ^ c1);
 }
 
+// One pass: agglomerate S segments (LEAF: the leaves [B0, B0 + S) of this block; else the open roots of the `nb`
+// source blocks whose counts / records start at src_cnt / src_rec) inside LDS, write every node that completes and
+// emit what stays open to (out_cnt, out_rec).  All 1024 threads of the workgroup call it together.
 template <bool LEAF>
-__global__ __launch_bounds__(1024) void lbvh_level_kernel(LevelArgs a)
+__device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, uint32_t n, uint32_t B0, uint32_t S,
+                                           const uint32_t* src_rec, uint32_t* out_cnt, uint32_t* out_rec)
 {
-    using C = LevelCfg<LEAF>;
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    using C = LevelCfgT<LEAF ? kLeafCap : kCap>;
     int* dl = reinterpret_cast<int*>(smem + C::oDl);
     int* bnd = reinterpret_cast<int*>(smem + C::oBnd);
     uint32_t* lock = smem + C::oLock;
@@ -92,47 +133,32 @@ __global__ __launch_bounds__(1024) void lbvh_level_kernel(LevelArgs a)
     uint32_t* s_desc = smem + C::oDesc;
     uint32_t* s_cc = smem + C::oCc;
     float* s_box = reinterpret_cast<float*>(smem + C::oBox);
-    uint32_t* ws = smem + C::oWs;      // [0..17) scan scratch
-    uint32_t* pref = smem + C::oWs + 32;  // [0..17) prefix of previous-level counts
-
+    uint32_t* ws = smem + C::oWs;            // [0..17) scan scratch
+    const uint32_t* pref = smem + C::oWs + 40;  // [0..64] prefix of the source blocks' counts (upper passes)
     const uint32_t tid = threadIdx.x;
-    const uint32_t n = a.n_dev ? *a.n_dev : a.n;
-    const uint32_t B0 = blockIdx.x * kLeafCap;  // leaf level only
-    uint32_t S;
 
-    if (LEAF) {
-        S = B0 < n ? min(kLeafCap, n - B0) : 0u;   // grids are sized for the largest possible n
-    } else {
-        if (tid < 64) {
-            const uint32_t pb = blockIdx.x * kUpperFan + tid;
-            uint32_t c = (tid < kUpperFan && pb < a.prev_blocks) ? a.prev_cnt[pb] : 0u;
-            c = min(c, kMaxOpen);
-            uint32_t incl = wave_incl_scan_u32(c, (int)tid);
-            if (tid < kUpperFan) pref[tid + 1] = incl;
-            if (tid == 0) pref[0] = 0;
-        }
-        __syncthreads();
-        S = pref[kUpperFan];
-    }
-
-    // record of local segment s at an upper level
+    // record of local segment s of an upper pass: source block = the last one whose prefix is <= s
     auto rec_ptr = [&](uint32_t s) -> const uint32_t* {
         uint32_t pb = 0;
 #pragma unroll
-        for (uint32_t k = 1; k < kUpperFan; k++) pb += (pref[k] <= s) ? 1u : 0u;
-        return a.prev_rec + ((size_t)(blockIdx.x * kUpperFan + pb) * kMaxOpen + (s - pref[pb])) * kRecDwords;
+        for (uint32_t step = kUpperFan / 2; step; step >>= 1) pb += (pref[pb + step] <= s) ? step : 0u;
+        return src_rec + ((size_t)pb * kMaxOpen + (s - pref[pb])) * kRecDwords;
     };
 
     for (uint32_t b = tid; b <= S; b += 1024) {
         lock[b] = kLockEmpty;
-        int g;
         if (LEAF) {
-            g = (int)B0 + (int)b - 1;
+            dl[b] = S ? delta_adjacent(a.codes, (int)B0 + (int)b - 1, n) : -1;
+        } else if (S == 0) {
+            dl[b] = -1;
+            bnd[b] = -1;
         } else {
-            g = (S == 0) ? -1 : ((b == 0) ? (int)rec_ptr(0)[0] - 1 : (int)rec_ptr(b - 1)[1]);
-            bnd[b] = g;
+            // the deltas at a segment's two ends travel in its record (they were computed one level below):
+            // boundary b is the left end of segment b, the last boundary the right end of segment S-1
+            const uint32_t* r = rec_ptr(b < S ? b : S - 1);
+            dl[b] = (int)(b < S ? r[10] : r[11]);
+            bnd[b] = b < S ? (int)r[0] - 1 : (int)r[1];
         }
-        dl[b] = S ? delta_adjacent(a.codes, g, n) : -1;
     }
     __syncthreads();
 
@@ -296,18 +322,113 @@ __global__ __launch_bounds__(1024) void lbvh_level_kernel(LevelArgs a)
                 const uint32_t osf = rg & 0xFFFFu, osl = rg >> 16;
                 const uint32_t f = LEAF ? B0 + osf : (uint32_t)(bnd[osf] + 1);
                 const uint32_t l = LEAF ? B0 + osl : (uint32_t)bnd[osl + 1];
-                uint4* o = reinterpret_cast<uint4*>(a.out_rec + ((size_t)blockIdx.x * kMaxOpen + pos) * kRecDwords);
-                o[0] = make_uint4(f, l, s_desc[id], s_cc[id]);
-                o[1] = make_uint4(__float_as_uint(s_box[0 * C::CAP + id]), __float_as_uint(s_box[1 * C::CAP + id]),
-                                  __float_as_uint(s_box[2 * C::CAP + id]), __float_as_uint(s_box[3 * C::CAP + id]));
-                o[2] = make_uint4(__float_as_uint(s_box[4 * C::CAP + id]), __float_as_uint(s_box[5 * C::CAP + id]), 0u, 0u);
+                uint4* o = reinterpret_cast<uint4*>(out_rec + (size_t)pos * kRecDwords);
+                store_sc1(o + 0, f, l, s_desc[id], s_cc[id]);
+                store_sc1(o + 1, __float_as_uint(s_box[0 * C::CAP + id]), __float_as_uint(s_box[1 * C::CAP + id]),
+                          __float_as_uint(s_box[2 * C::CAP + id]), __float_as_uint(s_box[3 * C::CAP + id]));
+                store_sc1(o + 2, __float_as_uint(s_box[4 * C::CAP + id]), __float_as_uint(s_box[5 * C::CAP + id]),
+                          (uint32_t)dl[osf], (uint32_t)dl[osl + 1]);
             }
             pos++;
         }
     }
     if (tid == 0) {
-        a.out_cnt[blockIdx.x] = min(total, kMaxOpen);
+        store_sc1(out_cnt, min(total, kMaxOpen));
         if (total > kMaxOpen) atomicOr(a.status, 1u);  // cannot happen: <= 2 * depth(62) open roots
+    }
+    __syncthreads();   // LDS is reused by the next pass of this workgroup
+}
+
+// prefix table of the open-root counts of `nb` (<= 64) source blocks -> pref[0..64] in LDS; returns their sum
+__device__ __forceinline__ uint32_t load_prefix(uint32_t* smem, const uint32_t* src_cnt, uint32_t nb)
+{
+    uint32_t* pref = smem + UpperCfg::oWs + 40;
+    const uint32_t tid = threadIdx.x;
+    if (tid < 64) {
+        uint32_t c = tid < nb ? src_cnt[tid] : 0u;
+        c = min(c, kMaxOpen);
+        const uint32_t incl = wave_incl_scan_u32(c, (int)tid);
+        pref[tid + 1] = incl;
+        if (tid == 0) pref[0] = 0;
+    }
+    __syncthreads();
+    return pref[kUpperFan];
+}
+
+// ---- level 0: one workgroup per 1024 leaves (grids are sized for the largest possible n)
+__global__ __launch_bounds__(1024, 8) void lbvh_leaf_kernel(LevelArgs a)   // <= 64 VGPRs: two workgroups per CU
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t n = a.n_dev ? *a.n_dev : a.n;
+    const uint32_t blk = blockIdx.x;
+    const uint32_t B0 = blk * kLeafCap;
+    const uint32_t S = B0 < n ? min(kLeafCap, n - B0) : 0u;
+    level_pass<true>(a, smem, n, B0, S, nullptr, a.cnt[0] + blk, a.rec[0] + (size_t)blk * kMaxOpen * kRecDwords);
+}
+
+// ---- all upper levels in one launch: one workgroup per level-1 block; the workgroup that completes the inputs of a
+// block of the next level carries on with that block
+__global__ __launch_bounds__(1024) void lbvh_upper_kernel(LevelArgs a)
+{
+    using C = UpperCfg;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* flag = smem + C::oWs + 32;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n = a.n_dev ? *a.n_dev : a.n;
+    uint32_t blk = blockIdx.x;
+
+    for (uint32_t lvl = 1; lvl < a.num_levels; lvl++) {
+        if (lvl > 1) {
+            // hand-off of this workgroup's records (sc1 write-through stores): every storing wave drains its stores,
+            // the workgroup meets, one lane takes a ticket; the last ticket acquires (invalidates this CU's L1) before
+            // the barrier lets the other waves read the group's records
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const uint32_t grp = blk / kUpperFan;
+            const uint32_t nb_in = min(kUpperFan, a.blocks[lvl - 1] - grp * kUpperFan);
+            if (tid == 0) {
+                const uint32_t ticket = __hip_atomic_fetch_add(a.arrive[lvl] + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool last = ticket == nb_in - 1;
+                if (last) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                *flag = last ? 1u : 0u;
+            }
+            __syncthreads();
+            if (*flag == 0) return;
+            blk = grp;
+        }
+        const uint32_t first = blk * kUpperFan;
+        const uint32_t nb = min(kUpperFan, a.blocks[lvl - 1] - first);
+        const uint32_t* src_cnt = a.cnt[lvl - 1] + first;
+        const uint32_t* src_rec = a.rec[lvl - 1] + (size_t)first * kMaxOpen * kRecDwords;
+        uint32_t* out_cnt = a.cnt[lvl] + blk;
+        uint32_t* out_rec = a.rec[lvl] + (size_t)blk * kMaxOpen * kRecDwords;
+        const uint32_t S = load_prefix(smem, src_cnt, nb);
+        if (S <= RT_LBVH_FAST_CAP) {
+            level_pass<false>(a, smem, n, 0, S, src_rec, out_cnt, out_rec);
+        } else {
+            // more open roots than one pass holds (deep trees: long runs of equal codes): kSubFan source blocks at a
+            // time (always fit: kSubFan * kMaxOpen <= CAP) into this block's scratch, then one pass over those results
+            constexpr uint32_t kSubs = kUpperFan / kSubFan;
+            uint32_t* sc = a.sub_cnt[lvl] + (size_t)blk * kSubs;
+            uint32_t* sr = a.sub_rec[lvl] + (size_t)blk * kSubs * kMaxOpen * kRecDwords;
+            for (uint32_t j = 0; j < kSubs; j++) {
+                const uint32_t sfirst = j * kSubFan;
+                const uint32_t snb = sfirst < nb ? min(kSubFan, nb - sfirst) : 0u;
+                const uint32_t SS = load_prefix(smem, src_cnt + sfirst, snb);
+                level_pass<false>(a, smem, n, 0, SS, src_rec + (size_t)sfirst * kMaxOpen * kRecDwords, sc + j,
+                                  sr + (size_t)j * kMaxOpen * kRecDwords);
+            }
+            // this workgroup's own stores, read back by its other waves: drain, make them visible, meet
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const uint32_t S2 = load_prefix(smem, sc, kSubs);
+            level_pass<false>(a, smem, n, 0, S2, sr, out_cnt, out_rec);
+        }
     }
 }
 
@@ -336,15 +457,29 @@ LevelPlan lbvh_level_plan(uint32_t n)
     LevelPlan p;
     p.num_levels = 0;
     size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     uint32_t blocks = (n + kLeafCap - 1) / kLeafCap;
     if (blocks == 0) blocks = 1;
+    // the arrival counters of all levels first, contiguous: the build's init kernel zeroes [arrive_off, +arrive_bytes)
+    p.arrive_off = off;
+    {
+        uint32_t b = blocks;
+        size_t words = 0;
+        for (uint32_t k = 0; k < kMaxLevels; k++) { words += b; if (b == 1) break; b = (b + kUpperFan - 1) / kUpperFan; }
+        p.arrive_bytes = words * 4;
+        off += (p.arrive_bytes + 255) / 256 * 256;
+    }
+    size_t arrive = p.arrive_off;
+    constexpr uint32_t kSubs = kUpperFan / kSubFan;
     while (true) {
         const uint32_t k = p.num_levels++;
         p.blocks[k] = blocks;
-        p.cnt_off[k] = off;
-        off += ((size_t)blocks * 4 + 255) / 256 * 256;
-        p.rec_off[k] = off;
-        off += (size_t)blocks * kMaxOpen * kRecDwords * 4;
+        p.arrive_lvl[k] = arrive;
+        arrive += (size_t)blocks * 4;
+        p.cnt_off[k] = take((size_t)blocks * 4);
+        p.rec_off[k] = take((size_t)blocks * kMaxOpen * kRecDwords * 4);
+        p.sub_cnt_off[k] = k ? take((size_t)blocks * kSubs * 4) : 0;
+        p.sub_rec_off[k] = k ? take((size_t)blocks * kSubs * kMaxOpen * kRecDwords * 4) : 0;
         if (blocks == 1 || p.num_levels == kMaxLevels) break;
         blocks = (blocks + kUpperFan - 1) / kUpperFan;
     }
@@ -358,16 +493,16 @@ hipError_t launch_lbvh_levels(const rt_triangle* tris, const uint32_t* codes, co
 {
     static PerDeviceOnce once;
     const hipError_t attr_err = once([] {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lbvh_level_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LevelCfg<false>::kBytes);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lbvh_leaf_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LeafCfg::kBytes);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lbvh_level_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LevelCfg<true>::kBytes);
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lbvh_upper_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)UpperCfg::kBytes);
         return e;
     });
     if (attr_err != hipSuccess) return attr_err;
 
-    if (n >= 2 || n == 1) {
+    if (n >= 1) {
         const LevelPlan p = lbvh_level_plan(n);
         char* base = static_cast<char*>(level_scratch);
         LevelArgs a;
@@ -379,17 +514,20 @@ hipError_t launch_lbvh_levels(const rt_triangle* tris, const uint32_t* codes, co
         a.leaves = leaves;
         a.nodes = nodes;
         a.status = status;
-        for (uint32_t k = 0; k < p.num_levels; k++) {
-            a.prev_cnt = k ? reinterpret_cast<const uint32_t*>(base + p.cnt_off[k - 1]) : nullptr;
-            a.prev_rec = k ? reinterpret_cast<const uint32_t*>(base + p.rec_off[k - 1]) : nullptr;
-            a.prev_blocks = k ? p.blocks[k - 1] : 0;
-            a.out_cnt = reinterpret_cast<uint32_t*>(base + p.cnt_off[k]);
-            a.out_rec = reinterpret_cast<uint32_t*>(base + p.rec_off[k]);
-            if (k == 0)
-                lbvh_level_kernel<true><<<p.blocks[k], 1024, LevelCfg<true>::kBytes, st>>>(a);
-            else
-                lbvh_level_kernel<false><<<p.blocks[k], 1024, LevelCfg<false>::kBytes, st>>>(a);
+        a.num_levels = p.num_levels;
+        for (uint32_t k = 0; k < kMaxLevels; k++) {
+            const bool on = k < p.num_levels;
+            a.blocks[k] = on ? p.blocks[k] : 0;
+            a.cnt[k] = on ? reinterpret_cast<uint32_t*>(base + p.cnt_off[k]) : nullptr;
+            a.rec[k] = on ? reinterpret_cast<uint32_t*>(base + p.rec_off[k]) : nullptr;
+            a.arrive[k] = on ? reinterpret_cast<uint32_t*>(base + p.arrive_lvl[k]) : nullptr;
+            a.sub_cnt[k] = on && k ? reinterpret_cast<uint32_t*>(base + p.sub_cnt_off[k]) : nullptr;
+            a.sub_rec[k] = on && k ? reinterpret_cast<uint32_t*>(base + p.sub_rec_off[k]) : nullptr;
         }
+        // the arrival counters must be zero: the caller's init kernel clears them (rt_run_bottom_up_build), see
+        // lbvh_arrive_region()
+        lbvh_leaf_kernel<<<p.blocks[0], 1024, LeafCfg::kBytes, st>>>(a);
+        if (p.num_levels > 1) lbvh_upper_kernel<<<p.blocks[1], 1024, UpperCfg::kBytes, st>>>(a);
     }
     if (n < 2 || n_dev) lbvh_tiny_kernel<<<1, 64, 0, st>>>(leaves, nodes, n, n_dev);
     return hipGetLastError();

@@ -34,10 +34,13 @@ BuLayout bu_layout(uint32_t n)
 
 static inline int hip_rc(hipError_t e) { return e == hipSuccess ? RT_OK : RT_ERR_HIP_BASE - (int)e; }
 
-// one launch for the build's tiny initialisations: status words = 0 and the ordered-int "empty" scene box
-// (BuildWrapper.cu:288-303 does these with 6 memset / memcpy calls)
-__global__ void build_init_kernel(uint32_t* status, int* aabb, int* aabb_parts, uint32_t n)
+// one launch for the build's tiny initialisations: status words = 0, the ordered-int "empty" scene box
+// (BuildWrapper.cu:288-303 does these with 6 memset / memcpy calls) and the LBVH hierarchy's arrival counters = 0
+__global__ __launch_bounds__(256) void build_init_kernel(uint32_t* status, int* aabb, int* aabb_parts, uint32_t n,
+                                                         uint32_t* arrive, uint32_t arrive_words)
 {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < arrive_words; i += gridDim.x * 256) arrive[i] = 0;
+    if (blockIdx.x != 0) return;
     if (threadIdx.x < 8) status[threadIdx.x] = threadIdx.x == 1 ? n : 0;   // [1] = number of leaves (pairs: overwritten)
     if (threadIdx.x < 6) aabb[threadIdx.x] = threadIdx.x < 3 ? 0x7f7fffff : (int)0x80800000;
     for (uint32_t i = threadIdx.x; i < kAabbParts * 6; i += blockDim.x) aabb_parts[i] = (i % 6) < 3 ? 0x7f7fffff : (int)0x80800000;
@@ -119,7 +122,11 @@ int rt_run_bottom_up_build(const rt_build_input* input, const rt_arguments* args
     uint32_t* tmpv = reinterpret_cast<uint32_t*>(s + L.tmp_vals);
 
     int* aabb_parts = reinterpret_cast<int*>(s + L.aabb_parts);
-    build_init_kernel<<<1, 64, 0, st>>>(status, p_aabb, aabb_parts, n);
+    const LevelPlan lp = lbvh_level_plan(n);
+    const uint32_t arrive_words = (uint32_t)(lp.arrive_bytes / 4);
+    const uint32_t init_blocks = arrive_words > 256 ? (arrive_words / 1024 < 64 ? arrive_words / 1024 + 1 : 64) : 1;
+    build_init_kernel<<<init_blocks, 256, 0, st>>>(status, p_aabb, aabb_parts, n,
+                                                   reinterpret_cast<uint32_t*>(s + L.levels + lp.arrive_off), arrive_words);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = launch_scene_aabb(input->triangles_in, n, aabb_parts, st, kAabbParts);
     // with --pairs the number of leaves L <= n is only known on the device (status[1]); the reference copies it
@@ -238,7 +245,7 @@ const char* rt_error_string(int code)
 
 const char* rt_version_string(void)
 {
-    return "rt_amd gfx950 | sort: LSD 4x8bit, tile 4096 | lbvh: LDS agglomerative, 1024 leaves/wg, fan 16, hybrid SAH top | "
+    return "rt_amd gfx950 | sort: LSD 4x8bit, tile 4096 | lbvh: LDS agglomerative, one launch (1024 leaves/wg, last-arriver levels, fan 64), hybrid SAH top | "
            "sah: 4x4x4 grid + level-synchronous binned SAH, wave-per-task below 64 items, pairs, splits | "
            "trace: wave64 8x8 tiles, two-phase schedule, LDS stack 16";
 }

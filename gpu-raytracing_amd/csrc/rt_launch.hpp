@@ -50,17 +50,22 @@ SortScratch sort_scratch_layout(uint32_t n);
 
 // ---- LBVH level geometry (lbvh_levels.hip)
 constexpr uint32_t kLeafCap = 1024;   // leaves per workgroup at the leaf level
-constexpr uint32_t kUpperFan = 16;    // previous-level workgroups folded by one upper-level workgroup
-constexpr uint32_t kMaxOpen = 128;    // open sub-tree roots a workgroup can emit (>= 2 * max tree depth 62)
-constexpr uint32_t kUpperCap = kUpperFan * kMaxOpen;  // 2048 segments per upper-level workgroup
-constexpr uint32_t kRecDwords = 12;   // segment record: f, l, desc, cc, min[3], max[3], pad[2]
-constexpr uint32_t kMaxLevels = 8;
+constexpr uint32_t kUpperCap = 2048;  // open roots one upper-level pass holds in LDS
+constexpr uint32_t kUpperFan = 64;    // previous-level blocks folded by one upper-level block (when their open roots fit one pass)
+constexpr uint32_t kSubFan = 16;      // ... else in sub-passes of this many blocks (kSubFan * kMaxOpen always fits)
+constexpr uint32_t kMaxOpen = 128;    // open sub-tree roots a block can emit (>= 2 * max tree depth 62)
+constexpr uint32_t kRecDwords = 12;   // segment record: f, l, desc, cc, min[3], max[3], delta at its left end, delta at its right end
+constexpr uint32_t kMaxLevels = 6;    // 2^28 leaves -> 2^18 blocks -> 4096 -> 64 -> 1
 
 struct LevelPlan {
     uint32_t num_levels;
     uint32_t blocks[kMaxLevels];
-    size_t cnt_off[kMaxLevels];  // uint32[blocks]
-    size_t rec_off[kMaxLevels];  // uint32[blocks][kMaxOpen][kRecDwords]
+    size_t cnt_off[kMaxLevels];      // uint32[blocks]
+    size_t rec_off[kMaxLevels];      // uint32[blocks][kMaxOpen][kRecDwords]
+    size_t arrive_lvl[kMaxLevels];   // uint32[blocks] tickets taken at this level's blocks (inside the arrive region)
+    size_t sub_cnt_off[kMaxLevels];  // fallback scratch of the upper levels
+    size_t sub_rec_off[kMaxLevels];
+    size_t arrive_off, arrive_bytes; // all arrival counters, contiguous: must be zero when the build kernel starts
     size_t total;
 };
 LevelPlan lbvh_level_plan(uint32_t n);

@@ -1,6 +1,8 @@
 """GPU parity tests proper: the HIP path (through the C ABI of include/rt_abi.h) against the CPU oracle on the
 same seeded inputs.  Integer / index work is bit-exact; boxes are exact float equality; kDepth / kBoxtests /
 kTriangleTests frames are byte-exact; kDiffuse is within 1 LSB per channel (double pow() on device vs libm)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -299,3 +301,53 @@ def test_full_size_10m_build(rt, scenes, ora):
     assert (g["codes"] == o["codes"]).all() and (g["indices"] == o["indices"]).all()
     assert_nodes_equal(g["nodes"], o["nodes"], "10M")
     assert g["leaves"].tobytes() == o["leaves"].tobytes()
+
+
+def test_lbvh_hierarchy_handoff_alternating_scenes(rt, scenes, ora):
+    """The one-launch hierarchy hands open-root records from workgroup to workgroup (release -> ticket -> acquire).
+    Rebuilding DIFFERENT scenes of the same size in the SAME buffers would expose a stale read of the previous build's
+    records (same addresses, different bytes): 12 alternating builds, 196 leaf blocks -> 4 level-1 blocks -> root,
+    every Node word against the oracle each time."""
+    import torch
+    from helpers import assert_nodes_equal
+    sets = [scenes.soup(200000, 5), scenes.soup(200000, 6, dup_fraction=0.6), scenes.soup(200000, 7, dup_fraction=0.0)]
+    n = sets[0].shape[0]
+    oracles = [ora.build_bvh(t) for t in sets]
+    inp = rt.BuildInput.allocate(sets[0])
+    lay = rt.scratch_layout(n)
+    for it in range(12):
+        k = (it * 2 + it // 3) % 3
+        inp.triangles_in.copy_(rt.to_device(sets[k]))
+        rt.RunBottomUpBuild(inp)
+        torch.cuda.synchronize()
+        assert int(rt.to_host(inp.scratch, np.uint32, 8, lay.status)[0]) == 0
+        assert_nodes_equal(rt.to_host(inp.nodes_out, rt.NODE, 2 * (n - 1)), oracles[k]["nodes"], f"iteration {it} scene {k}")
+        assert rt.to_host(inp.triangles_out, rt.TRIANGLE_PAIR, n).tobytes() == oracles[k]["leaves"].tobytes()
+
+
+@pytest.mark.parametrize("scene,n", [("soup", 70000), ("soup", 200000), ("grid", 0), ("dups", 150000)])
+def test_lbvh_subpass_path(rt, scenes, ora, scene, n):
+    """An upper-level block whose 64 source blocks hold more open roots than one LDS pass takes them kSubFan blocks at
+    a time and merges the results.  Real scenes stay far below the threshold (about 10 open roots per 1024-leaf
+    block against 16 needed), so the path is exercised through librt_amd_smallcap.so: the same sources with the
+    threshold at 48 open roots (csrc/Makefile) -- every multi-block group then takes it.  Same tree, bit for bit."""
+    import ctypes
+    import torch
+    from helpers import assert_nodes_equal
+    path = os.path.join(os.path.dirname(rt.LIB_PATH), "librt_amd_smallcap.so")
+    L = ctypes.CDLL(path)
+    L.rt_run_bottom_up_build.restype = ctypes.c_int
+    L.rt_run_bottom_up_build.argtypes = [ctypes.POINTER(rt._BuildInput), ctypes.POINTER(rt._Arguments), ctypes.c_int, ctypes.c_void_p]
+    tris = {"soup": lambda: scenes.soup(n, 11), "grid": lambda: scenes.grid_mesh(330, 4),
+            "dups": lambda: scenes.soup(n, 12, dup_fraction=0.9)}[scene]()
+    m = tris.shape[0]
+    inp = rt.BuildInput.allocate(tris)
+    inp.nodes_out.fill_(0xCD)
+    ci = rt._BuildInput(rt._ptr(inp.triangles_in), rt._ptr(inp.triangles_out), m, rt._ptr(inp.nodes_out), rt._ptr(inp.scratch))
+    ca = rt._Arguments(rt.kBottomUp, 0, 0, 0)
+    for _ in range(2):
+        assert L.rt_run_bottom_up_build(ctypes.byref(ci), ctypes.byref(ca), 0, rt._stream_ptr(None)) == 0
+    torch.cuda.synchronize()
+    o = ora.build_bvh(tris)
+    assert int(rt.to_host(inp.scratch, np.uint32, 8, rt.scratch_layout(m).status)[0]) == 0
+    assert_nodes_equal(rt.to_host(inp.nodes_out, rt.NODE, 2 * (m - 1)), o["nodes"], f"{scene} {m} (sub-pass path)")
