@@ -164,6 +164,59 @@ __global__ __launch_bounds__(256) void morton_kernel(uint32_t* __restrict__ code
     values[gid] = gid;
 }
 
+// Morton codes + the tile histograms of the sort's first pass in one launch: a workgroup owns one sort tile (4096
+// triangles, 16 per thread: each lane reads its 36-byte triangle directly -- neighbouring lanes use the rest of every
+// line) and counts the low BITS bits of its codes in LDS exactly as sort_upsweep_kernel would.
+template <uint32_t BITS>
+__global__ __launch_bounds__(256) void morton_hist_kernel(uint32_t* __restrict__ codes, uint32_t* __restrict__ values,
+                                                          const float* __restrict__ f, const int* __restrict__ aabb,
+                                                          uint32_t n, uint32_t nparts, int* __restrict__ aabb_out,
+                                                          uint32_t* __restrict__ hist, uint32_t num_tiles)
+{
+    constexpr uint32_t RADIX = 1u << BITS;
+    __shared__ uint32_t h[RADIX];
+    __shared__ int sbox[6];
+    float bmin[3], bmax[3];
+    for (uint32_t d = threadIdx.x; d < RADIX; d += 256) h[d] = 0;
+    fold_scene_box(aabb, nparts, sbox, bmin, bmax);   // (its barriers also order the zeroing of h)
+    if (aabb_out && blockIdx.x == 0 && threadIdx.x < 6) aabb_out[threadIdx.x] = sbox[threadIdx.x];
+    const uint32_t tile = blockIdx.x, base = tile * kSortTile;
+    const int lane = threadIdx.x & 63;
+    const float minx = bmin[0], miny = bmin[1], minz = bmin[2], maxx = bmax[0], maxy = bmax[1], maxz = bmax[2];
+#pragma unroll 4
+    for (uint32_t i = 0; i < kSortItems; i++) {
+        const uint32_t gid = base + i * kSortThreads + threadIdx.x;
+        const bool valid = gid < n;
+        uint32_t code = 0;
+        if (valid) {
+            float t[9];
+            load_tri9(f + (size_t)gid * 9, t);
+            float cx = ((t[0] + t[3]) + t[6]) / 3.0f;
+            float cy = ((t[1] + t[4]) + t[7]) / 3.0f;
+            float cz = ((t[2] + t[5]) + t[8]) / 3.0f;
+            cx = (cx - minx) / (maxx - minx);
+            cy = (cy - miny) / (maxy - miny);
+            cz = (cz - minz) / (maxz - minz);
+            cx = fmaxf(0.0f, fminf(cx, 1.0f));
+            cy = fmaxf(0.0f, fminf(cy, 1.0f));
+            cz = fmaxf(0.0f, fminf(cz, 1.0f));
+            code = morton3d(cx, cy, cz);
+            codes[gid] = code;
+            values[gid] = gid;
+        }
+        const uint32_t d = code & (RADIX - 1);
+        const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+        if (__popcll(__ballot(valid && d == d0)) >= 8) {
+            const uint64_t m = match_digit<BITS>(d, valid);
+            if (valid && lane == __ffsll((unsigned long long)m) - 1) atomicAdd(&h[d], (uint32_t)__popcll(m));
+        } else if (valid) {
+            atomicAdd(&h[d], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d < RADIX; d += 256) hist[(size_t)d * num_tiles + tile] = h[d];
+}
+
 // ---------------------------------------------------------------------------------------------
 // --pairs: GenerateMortonCodesPairs (BottomUpBuilder.cu:117-164).  Candidate k = triangles (2k, 2k+1); it yields one
 // leaf (a merged quad, or a lone last triangle) or two.  The reference claims leaf slots with atomicAdd (arrival
@@ -310,6 +363,19 @@ hipError_t launch_morton(uint32_t* codes, uint32_t* values, const rt_triangle* t
     if (n == 0) return hipSuccess;
     morton_kernel<<<(n + 255) / 256, 256, 0, st>>>(codes, values, reinterpret_cast<const float*>(tris), aabb, n,
                                                    nparts ? nparts : 1u, aabb_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_morton_hist(uint32_t* codes, uint32_t* values, const rt_triangle* tris, const int* aabb, uint32_t n,
+                              hipStream_t st, uint32_t nparts, int* aabb_out, uint32_t* hist, uint32_t bits)
+{
+    if (n == 0) return hipSuccess;
+    const uint32_t tiles = sort_num_tiles(n);
+    const float* f = reinterpret_cast<const float*>(tris);
+    if (bits == 10)
+        morton_hist_kernel<10><<<tiles, 256, 0, st>>>(codes, values, f, aabb, n, nparts ? nparts : 1u, aabb_out, hist, tiles);
+    else
+        morton_hist_kernel<8><<<tiles, 256, 0, st>>>(codes, values, f, aabb, n, nparts ? nparts : 1u, aabb_out, hist, tiles);
     return hipGetLastError();
 }
 

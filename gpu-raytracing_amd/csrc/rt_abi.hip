@@ -134,14 +134,21 @@ int rt_run_bottom_up_build(const rt_build_input* input, const rt_arguments* args
     // grids are sized for n
     uint32_t* num_leaves = status + 1;
     const uint32_t* n_dev = pairs ? num_leaves : nullptr;
+    // The sort of the 30-bit Morton keys: 3 passes x 10 bits while the tables stay small (kSort3PassMaxTiles), else 4 x 8.
+    // An odd number of passes ends in the other buffer pair, so the Morton kernels then write into the temporaries.
+    // Without --pairs the Morton kernel also produces the first pass's tile histograms (one launch fewer).
+    const bool three = sort_num_tiles(n) <= kSort3PassMaxTiles;
+    uint32_t* code_dst = three ? tmpk : morton;
+    uint32_t* value_dst = three ? tmpv : sorted;
     if (e == hipSuccess) {
         if (pairs)
-            e = launch_morton_pairs(morton, sorted, input->triangles_in, aabb_parts, n, reinterpret_cast<uint8_t*>(s + L.pair_flags),
+            e = launch_morton_pairs(code_dst, value_dst, input->triangles_in, aabb_parts, n, reinterpret_cast<uint8_t*>(s + L.pair_flags),
                                     reinterpret_cast<uint32_t*>(s + L.pair_sums), num_leaves, st, kAabbParts, p_aabb);
         else
-            e = launch_morton(morton, sorted, input->triangles_in, aabb_parts, n, st, kAabbParts, p_aabb);
+            e = launch_morton_hist(code_dst, value_dst, input->triangles_in, aabb_parts, n, st, kAabbParts, p_aabb,
+                                   sort_hist_table(s + L.sort, n), three ? 10 : 8);
     }
-    if (e == hipSuccess) e = launch_radix_sort(morton, sorted, tmpk, tmpv, n, s + L.sort, st, n_dev);
+    if (e == hipSuccess) e = launch_radix_sort(morton, sorted, tmpk, tmpv, n, s + L.sort, st, n_dev, three ? 30 : 32, !pairs);
     if (e == hipSuccess)
         e = launch_lbvh_levels(input->triangles_in, morton, sorted, n, input->triangles_out, input->nodes_out,
                                s + L.levels, status, st, n_dev);
@@ -245,7 +252,7 @@ const char* rt_error_string(int code)
 
 const char* rt_version_string(void)
 {
-    return "rt_amd gfx950 | sort: LSD 4x8bit, tile 4096 | lbvh: LDS agglomerative, one launch (1024 leaves/wg, last-arriver levels, fan 64), hybrid SAH top | "
+    return "rt_amd gfx950 | sort: LSD 3x10bit Morton keys (4x8bit generic), tile 4096 | lbvh: LDS agglomerative, one launch (1024 leaves/wg, last-arriver levels, fan 64), hybrid SAH top | "
            "sah: 4x4x4 grid + level-synchronous binned SAH, wave-per-task below 64 items, pairs, splits | "
            "trace: wave64 8x8 tiles, two-phase schedule, LDS stack 16";
 }

@@ -77,6 +77,20 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
     return v;
 }
 
+// lanes (among `valid` ones) whose BITS-bit digit equals mine (the radix sort's ballot ranking)
+template <uint32_t BITS>
+__device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid)
+{
+    uint64_t m = __ballot(valid);
+#pragma unroll
+    for (uint32_t b = 0; b < BITS; b++) {
+        const bool bit = (d >> b) & 1u;
+        const uint64_t bal = __ballot(bit);
+        m &= bit ? bal : ~bal;
+    }
+    return m;
+}
+
 // exclusive scan of one value per thread over a block of NT threads (NT multiple of 64, <= 1024).
 // `ws` is NT/64 + 1 words of LDS.  Returns the exclusive prefix; *total gets the block sum.
 template <int NT>
