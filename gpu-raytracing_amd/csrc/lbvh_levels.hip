@@ -34,6 +34,8 @@
 // the OWNING node; w12 = parent:29|count:3 of a pair is written by whoever completes the pair's parent
 // (it knows the parent slot; the counts travel with the segment as 2 bits).  Every dword of every
 // slot is written exactly once, so no write ordering between threads is needed.
+#include <type_traits>
+
 #include "rt_device.hpp"
 #include "rt_launch.hpp"
 #include "rt_pairing.hpp"
@@ -75,24 +77,26 @@ struct LevelArgs {
     uint32_t* sub_rec[kMaxLevels];
 };
 
-template <uint32_t CAP_>
+template <uint32_t CAP_, uint32_t NT_, bool STAGE_>
 struct LevelCfgT {
     static constexpr uint32_t CAP = CAP_;
-    static constexpr uint32_t PER = (CAP + 1 + 1023) / 1024;  // boundaries per thread in the final compaction
+    static constexpr uint32_t NT = NT_;                       // threads of the workgroup
+    static constexpr uint32_t PER = (CAP + 1 + NT - 1) / NT;  // boundaries per thread in the final compaction
     // LDS carve (dwords)
     static constexpr uint32_t oDl = 0;                 // int   [CAP+1]  delta at boundary b
-    static constexpr uint32_t oBnd = oDl + CAP + 4;    // int   [CAP+1]  last leaf left of boundary b
-    static constexpr uint32_t oLock = oBnd + CAP + 4;  // u32   [CAP+1]
-    static constexpr uint32_t oRange = oLock + CAP + 4;  // u32 [CAP]  sf | sl << 16
+    static constexpr uint32_t oBnd = oDl + CAP + 4;    // int   [CAP+1]  last leaf left of boundary b (upper passes only)
+    static constexpr uint32_t oLock = oBnd + (STAGE_ ? 0 : CAP + 4);  // u32   [CAP+1]
+    static constexpr uint32_t oRange = oLock + CAP + 4;  // u32 [CAP]  sf | sl << 15 | cc << 30
     static constexpr uint32_t oDesc = oRange + CAP;
-    static constexpr uint32_t oCc = oDesc + CAP;
-    static constexpr uint32_t oBox = oCc + CAP;        // float [6][CAP]
+    static constexpr uint32_t oBox = oDesc + CAP;      // float [6][CAP]
     static constexpr uint32_t oWs = oBox + 6 * CAP;    // scan workspace [0, 32), hand-off flag [32], prefix table [40, 40 + 65)
-    static constexpr uint32_t kDwords = oWs + 40 + kUpperFan + 8;
+    static constexpr uint32_t oStage = oWs + 40 + kUpperFan + 8;   // leaf pass only: the block's node pairs, 16 dwords each
+    static constexpr uint32_t kDwords = oStage + (STAGE_ ? 16 * CAP : 0);
     static constexpr size_t kBytes = (size_t)kDwords * 4;
 };
-typedef LevelCfgT<kLeafCap> LeafCfg;    // 50 KB of LDS: two 1024-thread workgroups per CU at the leaf level
-typedef LevelCfgT<kCap> UpperCfg;       // 98 KB: the upper levels run a handful of workgroups
+typedef LevelCfgT<kLeafCap, kLeafThreads, true> LeafCfg;   // 52.5 KB of LDS (32 KB of it the node staging area): three 512-thread workgroups per CU
+typedef LevelCfgT<kCap, 1024, false> UpperCfg;             // 90 KB: the upper levels run a handful of workgroups
+static_assert(3 * LeafCfg::kBytes <= 160 * 1024, "three leaf workgroups per CU");
 
 // Hand-off stores: write-through at agent scope (`sc1`), so that the records a workgroup leaves for the next level are
 // in memory once its `s_waitcnt vmcnt(0)` returns -- without an L2 write-back per workgroup (an agent-scope release
@@ -125,13 +129,13 @@ template <bool LEAF>
 __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, uint32_t n, uint32_t B0, uint32_t S,
                                            const uint32_t* src_rec, uint32_t* out_cnt, uint32_t* out_rec)
 {
-    using C = LevelCfgT<LEAF ? kLeafCap : kCap>;
+    using C = typename std::conditional<LEAF, LeafCfg, UpperCfg>::type;
+    constexpr uint32_t NT = C::NT;
     int* dl = reinterpret_cast<int*>(smem + C::oDl);
     int* bnd = reinterpret_cast<int*>(smem + C::oBnd);
     uint32_t* lock = smem + C::oLock;
     uint32_t* s_range = smem + C::oRange;
     uint32_t* s_desc = smem + C::oDesc;
-    uint32_t* s_cc = smem + C::oCc;
     float* s_box = reinterpret_cast<float*>(smem + C::oBox);
     uint32_t* ws = smem + C::oWs;            // [0..17) scan scratch
     const uint32_t* pref = smem + C::oWs + 40;  // [0..64] prefix of the source blocks' counts (upper passes)
@@ -145,7 +149,17 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
         return src_rec + ((size_t)pb * kMaxOpen + (s - pref[pb])) * kRecDwords;
     };
 
-    for (uint32_t b = tid; b <= S; b += 1024) {
+    // Leaf pass: every node this block completes has its Karras index inside the block's leaf range, so the block's
+    // node pairs are assembled in LDS (stage[pair - B0][16 dwords]) and leave in ONE coalesced sweep at the end: 4 x
+    // 16-byte stores per pair instead of the ~12 scattered store instructions per merge that made this kernel bound
+    // by vector-memory instruction issue (70 store instructions per wave, SQ_WAIT_INST_ANY 47 %: profiles/r02_build_pmc.txt;
+    // a wave store costs per lane whatever its width: profiles/r02_ta_microbench.txt).
+    // dword 7 (w28 of slot 0: child | type, never 0 for a real slot) doubles as the "pair was completed here" marker.
+    uint32_t* stage = smem + C::oStage;
+    if (LEAF) {
+        for (uint32_t j = tid; j < C::CAP; j += NT) stage[j * 16 + 7] = 0u;
+    }
+    for (uint32_t b = tid; b <= S; b += NT) {
         lock[b] = kLockEmpty;
         if (LEAF) {
             dl[b] = S ? delta_adjacent(a.codes, (int)B0 + (int)b - 1, n) : -1;
@@ -162,7 +176,7 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
     }
     __syncthreads();
 
-    for (uint32_t s0 = tid; s0 < S; s0 += 1024) {
+    for (uint32_t s0 = tid; s0 < S; s0 += NT) {
         uint32_t sf = s0, sl = s0, desc, cc;
         float bx[6];
         if (LEAF) {
@@ -228,9 +242,8 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
             const bool go_right = ldl < rdl;  // I am the LEFT child of my parent
             const uint32_t b = go_right ? sl + 1 : sf;
 
-            s_range[s0] = sf | (sl << 16);
+            s_range[s0] = sf | (sl << 15) | (cc << 30);
             s_desc[s0] = desc;
-            s_cc[s0] = cc;
 #pragma unroll
             for (int k = 0; k < 6; k++) s_box[k * C::CAP + s0] = bx[k];
             // my state is in LDS before the exchange makes me findable (one wave's DS ops retire in order)
@@ -241,7 +254,7 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
             lock[b] = kLockDone;
 
             const uint32_t orange = s_range[other];
-            const uint32_t odesc = s_desc[other], occ = s_cc[other];
+            const uint32_t odesc = s_desc[other], occ = orange >> 30;
             float ob[6];
 #pragma unroll
             for (int k = 0; k < 6; k++) ob[k] = s_box[k * C::CAP + other];
@@ -250,11 +263,11 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
             uint32_t Lsf, Rsl, Ldesc, Rdesc, Lcc, Rcc;
             float Lb[6], Rb[6];
             if (go_right) {
-                Lsf = sf; Rsl = orange >> 16; Ldesc = desc; Rdesc = odesc; Lcc = cc; Rcc = occ;
+                Lsf = sf; Rsl = (orange >> 15) & 0x7FFFu; Ldesc = desc; Rdesc = odesc; Lcc = cc; Rcc = occ;
 #pragma unroll
                 for (int k = 0; k < 6; k++) { Lb[k] = bx[k]; Rb[k] = ob[k]; }
             } else {
-                Lsf = orange & 0xFFFFu; Rsl = sl; Ldesc = odesc; Rdesc = desc; Lcc = occ; Rcc = cc;
+                Lsf = orange & 0x7FFFu; Rsl = sl; Ldesc = odesc; Rdesc = desc; Lcc = occ; Rcc = cc;
 #pragma unroll
                 for (int k = 0; k < 6; k++) { Lb[k] = ob[k]; Rb[k] = bx[k]; }
             }
@@ -265,7 +278,12 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
             const uint32_t idx = is_root ? 0u : (pl < pr ? lP : fP);  // Karras index of the new node
 
             const bool Lbox = (Ldesc >> 29) == RT_CHILD_BOX, Rbox = (Rdesc >> 29) == RT_CHILD_BOX;
-            uint32_t* nw = reinterpret_cast<uint32_t*>(a.nodes + (size_t)idx * 2);
+            // the new node's pair: box + descriptor of each child; then parent:29|count:3 of the children's own pairs
+            // (BottomUpBuilder.cu:204-213, :265, :282).  Leaf pass: into the staging area (the children's pairs were
+            // completed in this block too); upper passes: straight to memory (few nodes, indices anywhere).
+            uint32_t* nw = LEAF ? stage + (idx - B0) * 16 : reinterpret_cast<uint32_t*>(a.nodes + (size_t)idx * 2);
+            uint32_t* cl = LEAF ? stage + ((Ldesc & kIndexMask) / 2 - B0) * 16 : reinterpret_cast<uint32_t*>(a.nodes + (Ldesc & kIndexMask));
+            uint32_t* cr = LEAF ? stage + ((Rdesc & kIndexMask) / 2 - B0) * 16 : reinterpret_cast<uint32_t*>(a.nodes + (Rdesc & kIndexMask));
             nw[0] = __float_as_uint(Lb[0]); nw[1] = __float_as_uint(Lb[1]); nw[2] = __float_as_uint(Lb[2]);
             *reinterpret_cast<uint4*>(nw + 4) =
                 make_uint4(__float_as_uint(Lb[3]), __float_as_uint(Lb[4]), __float_as_uint(Lb[5]), Ldesc);
@@ -276,16 +294,13 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
                 nw[3] = (Lbox ? 2u : 1u) << 29;
                 nw[11] = (Rbox ? 2u : 1u) << 29;
             }
-            // parent:29|count:3 of the children's own pairs (BottomUpBuilder.cu:204-213, :265, :282)
             if (Lbox) {
-                uint32_t* cw = reinterpret_cast<uint32_t*>(a.nodes + (Ldesc & kIndexMask));
-                cw[3] = (idx * 2) | (((Lcc & 1u) ? 2u : 1u) << 29);
-                cw[11] = (idx * 2) | (((Lcc & 2u) ? 2u : 1u) << 29);
+                cl[3] = (idx * 2) | (((Lcc & 1u) ? 2u : 1u) << 29);
+                cl[11] = (idx * 2) | (((Lcc & 2u) ? 2u : 1u) << 29);
             }
             if (Rbox) {
-                uint32_t* cw = reinterpret_cast<uint32_t*>(a.nodes + (Rdesc & kIndexMask));
-                cw[3] = (idx * 2 + 1) | (((Rcc & 1u) ? 2u : 1u) << 29);
-                cw[11] = (idx * 2 + 1) | (((Rcc & 2u) ? 2u : 1u) << 29);
+                cr[3] = (idx * 2 + 1) | (((Rcc & 1u) ? 2u : 1u) << 29);
+                cr[11] = (idx * 2 + 1) | (((Rcc & 2u) ? 2u : 1u) << 29);
             }
 
             sf = Lsf;
@@ -301,6 +316,19 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
     }
     __syncthreads();
 
+    if (LEAF) {
+        // the completed pairs of this block, 16 bytes per lane, consecutive lanes on consecutive addresses.  A pair whose
+        // parent is completed at an upper level leaves with undefined w12 words (dwords 3 and 11); the upper-level
+        // kernel, which runs after this one, writes them -- as it writes every word of the pairs not completed here.
+        const uint4* st4 = reinterpret_cast<const uint4*>(stage);
+        uint4* dst = reinterpret_cast<uint4*>(a.nodes + (size_t)B0 * 2);
+#pragma unroll
+        for (uint32_t k = 0; k < 4 * C::CAP / NT; k++) {
+            const uint32_t c = tid + k * NT;          // 16-byte chunk; pair = c / 4
+            if ((stage[(c >> 2) * 16 + 7] >> 29) != 0u) dst[c] = st4[c];
+        }
+    }
+
     // open roots = rendezvous points where only one child ever arrived, in boundary (= leaf) order
     uint32_t ids[C::PER];
     uint32_t mine = 0;
@@ -312,18 +340,18 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
         mine += (v < kLockDone) ? 1u : 0u;
     }
     uint32_t total;
-    uint32_t pos = block_excl_scan_u32<1024>(mine, ws, &total);
+    uint32_t pos = block_excl_scan_u32<NT>(mine, ws, &total);
 #pragma unroll
     for (uint32_t j = 0; j < C::PER; j++) {
         const uint32_t id = ids[j];
         if (id < kLockDone) {
             if (pos < kMaxOpen) {
                 const uint32_t rg = s_range[id];
-                const uint32_t osf = rg & 0xFFFFu, osl = rg >> 16;
+                const uint32_t osf = rg & 0x7FFFu, osl = (rg >> 15) & 0x7FFFu;
                 const uint32_t f = LEAF ? B0 + osf : (uint32_t)(bnd[osf] + 1);
                 const uint32_t l = LEAF ? B0 + osl : (uint32_t)bnd[osl + 1];
                 uint4* o = reinterpret_cast<uint4*>(out_rec + (size_t)pos * kRecDwords);
-                store_sc1(o + 0, f, l, s_desc[id], s_cc[id]);
+                store_sc1(o + 0, f, l, s_desc[id], rg >> 30);
                 store_sc1(o + 1, __float_as_uint(s_box[0 * C::CAP + id]), __float_as_uint(s_box[1 * C::CAP + id]),
                           __float_as_uint(s_box[2 * C::CAP + id]), __float_as_uint(s_box[3 * C::CAP + id]));
                 store_sc1(o + 2, __float_as_uint(s_box[4 * C::CAP + id]), __float_as_uint(s_box[5 * C::CAP + id]),
@@ -355,8 +383,8 @@ __device__ __forceinline__ uint32_t load_prefix(uint32_t* smem, const uint32_t* 
     return pref[kUpperFan];
 }
 
-// ---- level 0: one workgroup per 1024 leaves (grids are sized for the largest possible n)
-__global__ __launch_bounds__(1024, 8) void lbvh_leaf_kernel(LevelArgs a)   // <= 64 VGPRs: two workgroups per CU
+// ---- level 0: one 512-thread workgroup per 512 leaves (grids are sized for the largest possible n)
+__global__ __launch_bounds__(kLeafThreads, 6) void lbvh_leaf_kernel(LevelArgs a)   // three workgroups per CU (LDS), 24 waves
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t n = a.n_dev ? *a.n_dev : a.n;
@@ -526,7 +554,7 @@ hipError_t launch_lbvh_levels(const rt_triangle* tris, const uint32_t* codes, co
         }
         // the arrival counters must be zero: the caller's init kernel clears them (rt_run_bottom_up_build), see
         // lbvh_arrive_region()
-        lbvh_leaf_kernel<<<p.blocks[0], 1024, LeafCfg::kBytes, st>>>(a);
+        lbvh_leaf_kernel<<<p.blocks[0], kLeafThreads, LeafCfg::kBytes, st>>>(a);
         if (p.num_levels > 1) lbvh_upper_kernel<<<p.blocks[1], 1024, UpperCfg::kBytes, st>>>(a);
     }
     if (n < 2 || n_dev) lbvh_tiny_kernel<<<1, 64, 0, st>>>(leaves, nodes, n, n_dev);

@@ -50,13 +50,14 @@ struct SortScratch {
 SortScratch sort_scratch_layout(uint32_t n);
 
 // ---- LBVH level geometry (lbvh_levels.hip)
-constexpr uint32_t kLeafCap = 1024;   // leaves per workgroup at the leaf level
+constexpr uint32_t kLeafCap = 512;    // leaves per workgroup at the leaf level
+constexpr uint32_t kLeafThreads = 512;
 constexpr uint32_t kUpperCap = 2048;  // open roots one upper-level pass holds in LDS
 constexpr uint32_t kUpperFan = 64;    // previous-level blocks folded by one upper-level block (when their open roots fit one pass)
 constexpr uint32_t kSubFan = 16;      // ... else in sub-passes of this many blocks (kSubFan * kMaxOpen always fits)
 constexpr uint32_t kMaxOpen = 128;    // open sub-tree roots a block can emit (>= 2 * max tree depth 62)
 constexpr uint32_t kRecDwords = 12;   // segment record: f, l, desc, cc, min[3], max[3], delta at its left end, delta at its right end
-constexpr uint32_t kMaxLevels = 6;    // 2^28 leaves -> 2^18 blocks -> 4096 -> 64 -> 1
+constexpr uint32_t kMaxLevels = 6;    // 2^28 leaves -> 2^19 blocks -> 8192 -> 128 -> 2 -> 1
 
 struct LevelPlan {
     uint32_t num_levels;
