@@ -18,10 +18,13 @@
 //   * the two children of a parent rendezvous on the boundary between them with ONE LDS exchange:
 //     the first arriver leaves its state (range, box, descriptor) in LDS and retires, the second
 //     emits the parent's two Node slots (each 32-byte slot = box + descriptor of one child) and
-//     climbs on.  A workgroup owns 1024 consecutive leaves; sub-trees that cannot finish inside it
+//     climbs on.  A workgroup owns 512 consecutive leaves; sub-trees that cannot finish inside it
 //     (their sibling lies in another workgroup) are emitted as "open roots" -- at most 2 x depth <= 124
-//     per workgroup, 10 on average on the bench mesh -- and the next level (64x fewer blocks) treats
+//     per workgroup, 9 on average on the bench mesh -- and the next level (64x fewer blocks) treats
 //     those as its leaves;
+//   * at the leaf level every completed node lies in the block's own index range, so the block's node
+//     pairs are assembled in LDS and written with one coalesced sweep (the scattered per-merge stores
+//     made the kernel vector-memory-issue bound: 70 store instructions per wave);
 //   * two launches build the whole hierarchy: the leaf level, then ALL upper levels: when a workgroup
 //     has written its block's open roots (write-through stores) it takes a ticket on the counter of
 //     the next level's block (one relaxed device atomic); the workgroup that takes the LAST ticket of a
