@@ -94,8 +94,18 @@ def launch_ranks(n: int) -> int:
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RT_BENCH_SELF_LAUNCHED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.setdefault("OMP_NUM_THREADS", "1")
-        out = None if r == 0 else sys.stderr           # only rank 0 prints the JSON line
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+        # only rank 0 prints the JSON line; its stdout is filtered below (communication libraries may chat on stdout)
+        out = subprocess.PIPE if r == 0 else sys.stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out,
+                                      text=(r == 0)))
+    import threading
+
+    def relay():
+        for line in procs[0].stdout:
+            (sys.stdout if line.startswith("{") else sys.stderr).write(line)
+            sys.stdout.flush()
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
     rc = 0
     alive = set(range(n))
     while alive:
@@ -110,6 +120,7 @@ def launch_ranks(n: int) -> int:
                 for q in alive:
                     procs[q].terminate()
         time.sleep(0.05)
+    th.join(timeout=10)
     return rc
 
 
