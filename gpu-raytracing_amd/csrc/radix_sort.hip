@@ -118,7 +118,10 @@ __global__ __launch_bounds__(256) void sort_downsweep_kernel(const uint32_t* __r
     __shared__ uint32_t skey[kSortTile], sval[kSortTile];
     __shared__ uint32_t ws[8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t tile = blockIdx.x;
+    // XCD-aware tile order: hardware deals workgroup b to XCD b % 8; give XCD x a contiguous run of tiles.  Consecutive
+    // tiles write consecutive runs of every digit's output region (64 bytes on average = half a line), so the two halves
+    // of a line now meet in ONE L2 instead of being written back separately by two XCDs.
+    const uint32_t tile = xcd_contiguous(blockIdx.x, gridDim.x);
 #pragma unroll
     for (int w = 0; w < 4; w++)
         for (uint32_t d = threadIdx.x; d < RADIX; d += 256) wave_hist[w][d] = 0;

@@ -77,6 +77,14 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
     return v;
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin (b -> XCD b % 8; observed, speed only -- MI355X_MICROARCH.md, dispatch):
+// map workgroup b of nb to a work item such that XCD x gets the contiguous range [x * nb/8 ..).  A bijection on [0, nb).
+__device__ __forceinline__ uint32_t xcd_contiguous(uint32_t b, uint32_t nb)
+{
+    const uint32_t per = nb >> 3, rem = nb & 7u, xcd = b & 7u, loc = b >> 3;
+    return xcd * per + min(xcd, rem) + loc;
+}
+
 // lanes (among `valid` ones) whose BITS-bit digit equals mine (the radix sort's ballot ranking)
 template <uint32_t BITS>
 __device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid)

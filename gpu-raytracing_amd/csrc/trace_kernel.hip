@@ -34,6 +34,7 @@
 
 #include "rt_device.hpp"
 #include "rt_launch.hpp"
+#include "rt_math.h"
 
 namespace rt {
 
@@ -402,7 +403,7 @@ __device__ __forceinline__ float compute_lod(const Ray& r, const Hit& h, float s
     const float dxx = fabsf(ux.x - uvs.x) * sx, dxy = fabsf(ux.y - uvs.y) * sy;
     const float dyx = fabsf(uy.x - uvs.x) * sx, dyy = fabsf(uy.y - uvs.y) * sy;
     const float max_change = fmaxf(sqrtf(dxx * dxx + dxy * dxy), sqrtf(dyx * dyx + dyy * dyy));
-    return fmaxf(0.0f, fminf(log2f(max_change), (float)tex.max_lod));
+    return fmaxf(0.0f, fminf(rt_log2f(max_change), (float)tex.max_lod));   // log2f: rt_math.h (bit-identical to the oracle)
 }
 // TangentMatrix (Tracer.cu:84-101)
 __device__ __forceinline__ void tangent_matrix(const Surface& s, V3 rows[3])
@@ -421,7 +422,7 @@ __device__ __forceinline__ void tangent_matrix(const Surface& s, V3 rows[3])
 // Bump2Normal (Tracer.cu:157-185)
 __device__ __forceinline__ V3 bump2normal(const rt_texture& tex, const V3 tbn[3], F2 uv, float lod)
 {
-    const float texel_step = powf(2.0f, lod);
+    const float texel_step = rt_exp2f(lod);   // powf(2.0f, lod): rt_math.h
     const float stx = texel_step / (float)tex.size_x[0], sty = texel_step / (float)tex.size_y[0];
     const U8x4 a = trilinear_sample(tex, F2{uv.x - stx * 0.5f, uv.y - sty * 0.5f}, lod);
     const U8x4 b = trilinear_sample(tex, F2{uv.x + stx * 0.5f, uv.y + 0.0f}, lod);
@@ -592,7 +593,7 @@ __device__ __forceinline__ void shade_sample(const TraceParams& p, const rt_came
     const float rx = nlx - (nx * 2.0f) * ndl, ry = nly - (ny * 2.0f) * ndl, rz = nlz - (nz * 2.0f) * ndl;
     // pow(max(dot(-dir, refl), 0.0), Ns): double max, double pow, narrowed by operator*(float, float3)
     const double sb = fmax((double)((-r.dx) * rx + (-r.dy) * ry + (-r.dz) * rz), 0.0);
-    float sp = (float)(1.0f * pow(sb, (double)mat.specular_exp));
+    float sp = (float)(1.0f * rt_pow_d(sb, (double)mat.specular_exp));   // pow: rt_math.h
     float odx = mat.diffuse.x, ody = mat.diffuse.y, odz = mat.diffuse.z;
     if (use_textures && mat.texture != -1) {              // (:432-445): BilinearSample(tex, uv, (int)lod)
         const rt_texture& tex = p.textures[mat.texture];

@@ -1,6 +1,6 @@
 """GPU parity tests proper: the HIP path (through the C ABI of include/rt_abi.h) against the CPU oracle on the
 same seeded inputs.  Integer / index work is bit-exact; boxes are exact float equality; kDepth / kBoxtests /
-kTriangleTests frames are byte-exact; kDiffuse is within 1 LSB per channel (double pow() on device vs libm)."""
+kTriangleTests frames are byte-exact, and so is kDiffuse (its double pow() is csrc/rt_math.h on both sides)."""
 import os
 
 import numpy as np
@@ -131,7 +131,7 @@ def test_trace_diffuse_and_material_id(name, built, scenes, ora):
     lo, hi = ora.ordered_to_float(o["aabb"][:3]), ora.ordered_to_float(o["aabb"][3:])
     cam = scenes.camera_for_box(lo, hi)
     light = tuple(float(x) for x in (hi + (hi - lo) * 0.5))
-    for rtype, tol in ((5, 1), (3, 0)):
+    for rtype, tol in ((5, 0), (3, 0)):     # kDiffuse too: the specular pow() is rt_math.h's on both sides
         gi, gc = gpu_trace(g, cam, 200, 150, rtype, attributes=at, materials=mats, light=light)
         oi, oc = ora.trace(o["leaves"], o["nodes"], 0, 2, cam, 200, 150, render_type=rtype, attributes=at,
                            materials=mats, light=light)
