@@ -98,53 +98,60 @@ __global__ __launch_bounds__(256) void sort_scan_wide_kernel(const uint32_t* __r
     if (threadIdx.x == 0) totals[d] = running;
 }
 
-template <uint32_t BITS>
-__global__ __launch_bounds__(256) void sort_downsweep_kernel(const uint32_t* __restrict__ keys_in,
-                                                             const uint32_t* __restrict__ vals_in,
-                                                             uint32_t* __restrict__ keys_out,
-                                                             uint32_t* __restrict__ vals_out, uint32_t n,
-                                                             uint32_t shift, uint32_t num_tiles,
-                                                             const uint32_t* __restrict__ offs,
-                                                             const uint32_t* __restrict__ totals,
-                                                             const uint32_t* n_dev)
+// NT threads per 4096-key tile: 256 (16 keys per thread) when there are many tiles, 512 (8 per thread) when there are few --
+// a 1M-key pass is 245 workgroups on 256 CUs, i.e. one workgroup's dependent chain (16 ranking rounds, each an LDS
+// read-modify-write) IS the kernel's duration; twice the waves halve the rounds.
+template <uint32_t BITS, uint32_t NT>
+__global__ __launch_bounds__(NT) void sort_downsweep_kernel(const uint32_t* __restrict__ keys_in,
+                                                            const uint32_t* __restrict__ vals_in,
+                                                            uint32_t* __restrict__ keys_out,
+                                                            uint32_t* __restrict__ vals_out, uint32_t n,
+                                                            uint32_t shift, uint32_t num_tiles,
+                                                            const uint32_t* __restrict__ offs,
+                                                            const uint32_t* __restrict__ totals,
+                                                            const uint32_t* n_dev)
 {
     constexpr uint32_t RADIX = 1u << BITS;
-    constexpr uint32_t DPT = RADIX / 256;        // digits per thread in the table phases (thread t owns digits t*DPT ...)
+    constexpr uint32_t NW = NT / 64;             // waves
+    constexpr uint32_t ITEMS = kSortTile / NT;   // keys per thread
+    constexpr uint32_t DPT = (RADIX + NT - 1) / NT;   // digits per thread in the table phases (thread t owns digits t*DPT ...)
+    static_assert(kSortTile % NT == 0 && (RADIX % NT == 0 || NT % RADIX == 0), "tile and digit split");
+    const bool owner = threadIdx.x * DPT < RADIX;     // (NT > RADIX: the upper threads own no digit)
     if (n_dev) n = *n_dev;
     // wave_hist[w][d]: first the running count of digit d inside wave w's chunk, later the position inside the
     // tile (sorted by digit) of wave w's first key with digit d.
-    __shared__ uint32_t wave_hist[4][RADIX];
+    __shared__ uint32_t wave_hist[NW][RADIX];
     __shared__ uint32_t glob[RADIX];             // global position of local position 0 of digit d's run (mod 2^32)
     __shared__ uint32_t skey[kSortTile], sval[kSortTile];
-    __shared__ uint32_t ws[8];
+    __shared__ uint32_t ws[NW + 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // XCD-aware tile order: hardware deals workgroup b to XCD b % 8; give XCD x a contiguous run of tiles.  Consecutive
     // tiles write consecutive runs of every digit's output region (64 bytes on average = half a line), so the two halves
     // of a line now meet in ONE L2 instead of being written back separately by two XCDs.
     const uint32_t tile = xcd_contiguous(blockIdx.x, gridDim.x);
 #pragma unroll
-    for (int w = 0; w < 4; w++)
-        for (uint32_t d = threadIdx.x; d < RADIX; d += 256) wave_hist[w][d] = 0;
+    for (uint32_t w = 0; w < NW; w++)
+        for (uint32_t d = threadIdx.x; d < RADIX; d += NT) wave_hist[w][d] = 0;
     // digit bases = exclusive scan of the digit totals
     uint32_t tot[DPT], tsum = 0;
 #pragma unroll
-    for (uint32_t j = 0; j < DPT; j++) { tot[j] = totals[threadIdx.x * DPT + j]; tsum += tot[j]; }
+    for (uint32_t j = 0; j < DPT; j++) { tot[j] = owner ? totals[threadIdx.x * DPT + j] : 0u; tsum += tot[j]; }
     uint32_t dummy;
-    uint32_t digit_base = block_excl_scan_u32<256>(tsum, ws, &dummy);  // ends with a barrier
+    uint32_t digit_base = block_excl_scan_u32<NT>(tsum, ws, &dummy);  // ends with a barrier
 
-    // wave w owns keys [base + w*1024, base + (w+1)*1024) in rounds of 64 consecutive keys, so
+    // wave w owns keys [base + w*ITEMS*64, base + (w+1)*ITEMS*64) in rounds of 64 consecutive keys, so
     // (wave, round, lane) order IS input order: stability.
-    const uint32_t wbase = tile * kSortTile + wave * (kSortItems * 64);
-    uint32_t k[kSortItems], v[kSortItems], rank[kSortItems];
+    const uint32_t wbase = tile * kSortTile + wave * (ITEMS * 64);
+    uint32_t k[ITEMS], v[ITEMS], rank[ITEMS];
 #pragma unroll
-    for (int i = 0; i < (int)kSortItems; i++) {
+    for (uint32_t i = 0; i < ITEMS; i++) {
         uint32_t idx = wbase + i * 64 + lane;
         k[i] = idx < n ? keys_in[idx] : 0u;
         v[i] = idx < n ? vals_in[idx] : 0u;
     }
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int i = 0; i < (int)kSortItems; i++) {
+    for (uint32_t i = 0; i < ITEMS; i++) {
         uint32_t idx = wbase + i * 64 + lane;
         const bool valid = idx < n;
         const uint32_t d = (k[i] >> shift) & (RADIX - 1);
@@ -159,32 +166,31 @@ __global__ __launch_bounds__(256) void sort_downsweep_kernel(const uint32_t* __r
     }
     __syncthreads();
     {
-        uint32_t c[DPT][4], csum = 0;
+        uint32_t c[DPT][NW], csum = 0;
 #pragma unroll
         for (uint32_t j = 0; j < DPT; j++) {
             const uint32_t d = threadIdx.x * DPT + j;
-            c[j][0] = wave_hist[0][d]; c[j][1] = wave_hist[1][d]; c[j][2] = wave_hist[2][d]; c[j][3] = wave_hist[3][d];
-            csum += c[j][0] + c[j][1] + c[j][2] + c[j][3];
+#pragma unroll
+            for (uint32_t w = 0; w < NW; w++) { c[j][w] = owner ? wave_hist[w][d] : 0u; csum += c[j][w]; }
         }
         uint32_t tile_total;
-        uint32_t lstart = block_excl_scan_u32<256>(csum, ws, &tile_total);
+        uint32_t lstart = block_excl_scan_u32<NT>(csum, ws, &tile_total);
 #pragma unroll
         for (uint32_t j = 0; j < DPT; j++) {
             const uint32_t d = threadIdx.x * DPT + j;
-            wave_hist[0][d] = lstart;
-            wave_hist[1][d] = lstart + c[j][0];
-            wave_hist[2][d] = lstart + c[j][0] + c[j][1];
-            wave_hist[3][d] = lstart + c[j][0] + c[j][1] + c[j][2];
-            glob[d] = digit_base + offs[(size_t)d * num_tiles + tile] - lstart;
-            lstart += c[j][0] + c[j][1] + c[j][2] + c[j][3];
-            digit_base += tot[j];
+            if (owner) {
+                glob[d] = digit_base + offs[(size_t)d * num_tiles + tile] - lstart;
+#pragma unroll
+                for (uint32_t w = 0; w < NW; w++) { wave_hist[w][d] = lstart; lstart += c[j][w]; }
+                digit_base += tot[j];
+            }
         }
     }
     __syncthreads();
     // local scatter: the tile sorted by digit in LDS, then written out in position order so that one store
     // instruction covers contiguous runs (a tile holds 16 keys per 8-bit digit on average: 64-byte runs)
 #pragma unroll
-    for (int i = 0; i < (int)kSortItems; i++) {
+    for (uint32_t i = 0; i < ITEMS; i++) {
         uint32_t idx = wbase + i * 64 + lane;
         if (idx < n) {
             const uint32_t d = (k[i] >> shift) & (RADIX - 1);
@@ -197,8 +203,8 @@ __global__ __launch_bounds__(256) void sort_downsweep_kernel(const uint32_t* __r
     const uint32_t tbase = tile * kSortTile;
     const uint32_t nvalid = tbase < n ? min(kSortTile, n - tbase) : 0u;
 #pragma unroll
-    for (int i = 0; i < (int)kSortItems; i++) {
-        const uint32_t j = i * kSortThreads + threadIdx.x;
+    for (uint32_t i = 0; i < ITEMS; i++) {
+        const uint32_t j = i * NT + threadIdx.x;
         if (j < nvalid) {
             const uint32_t key = skey[j];
             const uint32_t pos = glob[(key >> shift) & (RADIX - 1)] + j;
@@ -233,7 +239,9 @@ static void radix_pass(const uint32_t* sk, const uint32_t* sv, uint32_t* dk, uin
     if (!have_hist) sort_upsweep_kernel<BITS><<<tiles, kSortThreads, 0, st>>>(sk, n, shift, tiles, hist, n_dev);
     if (tiles <= 512) sort_scan_kernel<<<(1u << BITS) / 4, 256, 0, st>>>(hist, tiles, offs, dt);
     else sort_scan_wide_kernel<<<1u << BITS, 256, 0, st>>>(hist, tiles, offs, dt);
-    sort_downsweep_kernel<BITS><<<tiles, kSortThreads, 0, st>>>(sk, sv, dk, dv, n, shift, tiles, offs, dt, n_dev);
+    // 512 threads per tile (8 keys each): half the ranking rounds of the 256-thread form and fewer registers (more waves
+    // per SIMD); the dependent chain of one workgroup is what a pass over few tiles costs
+    sort_downsweep_kernel<BITS, 512><<<tiles, 512, 0, st>>>(sk, sv, dk, dv, n, shift, tiles, offs, dt, n_dev);
 }
 
 hipError_t launch_radix_sort(uint32_t* keys, uint32_t* vals, uint32_t* tmp_keys, uint32_t* tmp_vals, uint32_t n,

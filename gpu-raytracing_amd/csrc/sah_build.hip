@@ -1057,14 +1057,9 @@ __device__ __forceinline__ void wave_lds_sync()
 
 constexpr uint32_t kSmallWaves = 4;   // independent waves per workgroup (single-wave workgroups are dispatch bound)
 
-__global__ __launch_bounds__(kSmallWaves * 64) void sah_small_kernel(SahArgs a, uint32_t nsmall)
+__device__ __forceinline__ void sah_small_task(const SahArgs& a, SmallSmem& S, uint32_t task, uint32_t lane)
 {
-    __shared__ SmallSmem SS[kSmallWaves];
-    const uint32_t task = blockIdx.x * kSmallWaves + (threadIdx.x >> 6);
-    if (task >= nsmall) return;
-    SmallSmem& S = SS[threadIdx.x >> 6];
     const SahSmall R = a.small[task];
-    const uint32_t lane = threadIdx.x & 63;
     const uint32_t cnt = R.end - R.start, base = R.start;
     const int bias = (R.flags & 1u) ? -2 * (int)a.B : (int)(2 * kSahCells);
     const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -1237,6 +1232,20 @@ __global__ __launch_bounds__(kSmallWaves * 64) void sah_small_kernel(SahArgs a, 
     }
 }
 
+// The small tasks [first, H->small_count): a fixed grid, every wave takes tasks with a grid stride.  The count is read
+// on the device, so the launch needs no host round trip after the level loop (68 us between the last level and this
+// kernel in round 1's timeline); `first` > 0 only when a later batch of levels appended more tasks.
+__global__ __launch_bounds__(kSmallWaves * 64) void sah_small_kernel(SahArgs a, uint32_t first)
+{
+    __shared__ SmallSmem SS[kSmallWaves];
+    const uint32_t nsmall = a.H->small_count;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (uint32_t task = first + blockIdx.x * kSmallWaves + wave; task < nsmall; task += gridDim.x * kSmallWaves) {
+        sah_small_task(a, SS[wave], task, lane);
+        wave_lds_sync();
+    }
+}
+
 // top-tree leaves: copy child / count / type of the cell's sub-root (SharedTaskBuilder.cu:422-446; the reference
 // forces type Box, which breaks a cell that holds a single leaf -- the type is copied here)
 __global__ void sah_patch_top_kernel(SahArgs a, int records_in_status2)
@@ -1376,20 +1385,26 @@ hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, boo
     // balanced; the first batch adds a margin, later batches are short
     uint32_t batch = 3;
     for (uint32_t per_cell = a.B / kSahCells; per_cell > kSahSmall; per_cell >>= 1) batch++;
-    uint32_t nsmall = 0;
+    // After each batch of levels the small-task kernel and the top-tree patch are launched at once (their counts live on the
+    // device); only then does the host read the number of live tasks.  In the common case (the first batch finished every
+    // task) that read is the build's final synchronisation and nothing waits for it.
+    constexpr uint32_t kSmallGrid = 8192;
+    uint32_t small_done = 0;
     while (true) {
         for (uint32_t i = 0; i < batch && lvl + 1 < kSahMaxLevels; i++, lvl++) {
             sah_bin_kernel<<<chunks, 256, 0, st>>>(a, lvl);
             sah_split_kernel<<<split_blocks, kSplitWaves * 64, 0, st>>>(a, lvl);
             sah_partition_kernel<<<chunks, 256, 0, st>>>(a, lvl);
         }
+        sah_small_kernel<<<kSmallGrid, kSmallWaves * 64, 0, st>>>(a, small_done);
+        sah_patch_top_kernel<<<1, 128, 0, st>>>(a, splits ? 1 : 0);
         uint32_t live = 0, hdr[9] = {0};   // status[0..7] and small_count are adjacent in SahHeader
         static_assert(offsetof(SahHeader, small_count) == offsetof(SahHeader, status) + 32, "one copy reads both");
         e = hipMemcpyAsync(&live, &a.H->level_count[lvl], 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipMemcpyAsync(hdr, &a.H->status[0], sizeof hdr, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) return e;
-        nsmall = hdr[8];
+        small_done = hdr[8];
         if (status0) *status0 = hdr[0];
         if (hdr[0] != 0) return hipSuccess;          // a kernel flagged an incomplete build (kSahErrLocals): stop here
         if (live == 0) break;
@@ -1403,8 +1418,6 @@ hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, boo
         batch = 4;
     }
     if (levels_run) *levels_run = lvl;
-    if (nsmall) sah_small_kernel<<<(nsmall + kSmallWaves - 1) / kSmallWaves, kSmallWaves * 64, 0, st>>>(a, nsmall);
-    sah_patch_top_kernel<<<1, 128, 0, st>>>(a, splits ? 1 : 0);
     return hipGetLastError();
 }
 
