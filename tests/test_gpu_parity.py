@@ -351,3 +351,25 @@ def test_lbvh_subpass_path(rt, scenes, ora, scene, n):
     o = ora.build_bvh(tris)
     assert int(rt.to_host(inp.scratch, np.uint32, 8, rt.scratch_layout(m).status)[0]) == 0
     assert_nodes_equal(rt.to_host(inp.nodes_out, rt.NODE, 2 * (m - 1)), o["nodes"], f"{scene} {m} (sub-pass path)")
+
+
+@pytest.mark.parametrize("n", [511, 512, 513, 1025, 32767, 32768, 32769, 65537, 2097152, 2097153])
+def test_lbvh_level_and_sort_boundaries(rt, scenes, ora, n):
+    """Sizes on both sides of every geometry switch of the builder: one leaf block (512 leaves) / two; one upper block
+    (64 leaf blocks = 32,768 leaves) / two + a third level; 512 sort tiles (2,097,152 keys: 3 x 10-bit passes, the Morton
+    kernel writing into the temporaries) / 513 tiles (4 x 8-bit passes) with 4097 leaf blocks -> 65 -> 2 -> 1.  Node[],
+    leaves, sorted codes and indices bit-exact."""
+    import torch
+    from helpers import gpu_build, assert_nodes_equal
+    tris = scenes.soup(n, 21, dup_fraction=0.3 if n < 100000 else 0.05)
+    g = gpu_build(tris)
+    o = ora.build_bvh(tris)
+    assert (g["codes"] == o["codes"]).all() and (g["indices"] == o["indices"]).all()
+    assert_nodes_equal(g["nodes"], o["nodes"], f"n = {n}")
+    assert g["leaves"].tobytes() == o["leaves"].tobytes()
+    if n <= 65537:      # the same through the hybrid and the pairs builds (device-side leaf count L < n)
+        inp = rt.BuildInput.allocate(tris)
+        rt.RunBottomUpBuild(inp, rt.Arguments(build_type=rt.kBottomUp, enable_pairs=True))
+        torch.cuda.synchronize()
+        op = ora.build_pairs(tris)
+        assert_nodes_equal(rt.to_host(inp.nodes_out, rt.NODE, op["nodes"].shape[0]), op["nodes"], f"pairs n = {n}")
