@@ -26,8 +26,9 @@
 //   * 1/direction is computed once per ray (bit-identical to recomputing it per box: IEEE division);
 //   * test counters are wave-reduced and added with ONE 64-bit atomic pair per wave (reference: one
 //     atomic per ray, Tracer.cu:503);
-//   * workgroups are dealt to XCDs round-robin by the hardware, so the tile order is remapped to give
-//     each XCD a contiguous band of the image (its L2 then serves one region of the tree).
+//   * workgroups are dealt to XCDs round-robin by the hardware; the tile order is remapped so that an XCD
+//     takes runs of 8 consecutive workgroups (256 x 8 pixels) spread over the whole frame: neighbouring
+//     rays share an L2, and every XCD gets its share of the expensive parts of the image.
 // Compiled with -ffp-contract=off: results are bit-identical to the C oracle.
 #include <cstdio>
 #include <cstdlib>
@@ -622,9 +623,20 @@ void trace_kernel(TraceParams p)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
     // XCD-aware remap: hardware deals workgroup b to XCD b % 8; give XCD x a contiguous run of tiles.
+    // Tile order vs XCDs: hardware deals workgroup b to XCD b % 8.  XCD x takes chunks of kXcdChunk consecutive workgroups
+    // (8 x 4 tiles = a 256 x 8 pixel run: neighbouring rays meet in one L2) dealt round-robin over the whole frame, so
+    // every XCD sees every region of the image.  (Round 1 gave each XCD one contiguous eighth of the frame: fine for a
+    // uniform view, but a view whose cost is concentrated in part of the frame -- camera B: the foreground rows -- then
+    // runs on two or three XCDs while the others idle: 1297 vs 3490 Mrays/s serial, 2548 vs 5397 with frames in flight.)
+    // RT_TRACE_XCD_CHUNK overrides the chunk at compile time (tools/xcd_chunk_experiment.sh).
+#ifndef RT_TRACE_XCD_CHUNK
+#define RT_TRACE_XCD_CHUNK 8
+#endif
     const uint32_t nb = gridDim.x, bid = blockIdx.x;
-    const uint32_t per = nb >> 3, rem = nb & 7u, xcd = bid & 7u, loc = bid >> 3;
-    const uint32_t vb = xcd * per + min(xcd, rem) + loc;
+    constexpr uint32_t kXcdChunk = RT_TRACE_XCD_CHUNK;
+    const uint32_t full = nb / (8u * kXcdChunk) * (8u * kXcdChunk);   // (the last < 8 * chunk workgroups keep their index)
+    const uint32_t xcd = bid & 7u, loc = bid >> 3;
+    const uint32_t vb = bid < full ? (loc / kXcdChunk) * (8u * kXcdChunk) + xcd * kXcdChunk + (loc % kXcdChunk) : bid;
     const uint32_t tile = vb * kTraceWaves + wave;
 
     // lane -> pixel inside the 8x8 tile, Morton order
