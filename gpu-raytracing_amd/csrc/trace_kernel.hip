@@ -53,7 +53,7 @@ constexpr int kRenderDebugBoxCount = 100;
 constexpr int kRenderDebugBoxCount = -1;   // matches no render type: every use below folds away
 #endif
 // the wave runs a box step while  stepping * park_den >= parked * park_num  (else one leaf phase)
-constexpr int kParkNum = 4, kParkDen = 1;   // (round-2 sweep under the chunked XCD order: 4..8 equal on the LBVH, 4 is +5 % on the SAH tree: tools/sweep_park.sh)
+constexpr int kParkNum = 8, kParkDen = 1;   // (round-2 sweep under the chunked XCD order, tools/sweep_park.sh: 4..8 equal on the 1080p LBVH frame; 4 is +5 % on the SAH tree but -4 % on the 4K x 16 spp frame)
 
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
