@@ -41,7 +41,10 @@ namespace rt {
 
 constexpr int kStackLds = 16;    // LDS-resident stack entries per lane (bench scenes peak at 10)
 constexpr int kStackMax = 64;    // reference stack size (Tracer.cu:314)
-constexpr int kTraceWaves = 4;
+#ifndef RT_TRACE_WAVES
+#define RT_TRACE_WAVES 4
+#endif
+constexpr int kTraceWaves = RT_TRACE_WAVES;   // waves (8x8 tiles) per workgroup
 #ifndef RT_TRACE_MIN_WAVES
 #define RT_TRACE_MIN_WAVES 7   // waves per SIMD the register allocator must fit (72 VGPRs: no spills; 8 -> 64 VGPRs spills)
 #endif
