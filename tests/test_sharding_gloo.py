@@ -124,3 +124,18 @@ def test_band_bounds():
             assert b[0] == 0 and b[-1] == h and all(b[i] <= b[i + 1] for i in range(n))
             assert max(b[i + 1] - b[i] for i in range(n)) - min(b[i + 1] - b[i] for i in range(n)) <= 1
     assert sharding.band_bounds(1080, 8) == [0, 135, 270, 405, 540, 675, 810, 945, 1080]
+
+
+def test_bench_self_launcher_without_gpu_fails_fast():
+    """`python bench.py --gpus 2` with no launcher: the parent starts two rank processes before touching any GPU; on a
+    machine without one every rank reports it and the parent returns non-zero promptly (no hang, no orphan ranks)."""
+    import subprocess
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("this check is for the GPU-less container")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=180)
+    assert p.returncode != 0
+    assert "no GPU visible" in p.stderr and "stopping the other ranks" in p.stderr
+    assert not any(l.startswith("{") for l in p.stdout.splitlines())
