@@ -167,8 +167,8 @@ __global__ __launch_bounds__(256) void morton_kernel(uint32_t* __restrict__ code
 // Morton codes + the tile histograms of the sort's first pass in one launch: a workgroup owns one sort tile (4096
 // triangles, 16 per thread: each lane reads its 36-byte triangle directly -- neighbouring lanes use the rest of every
 // line) and counts the low BITS bits of its codes in LDS exactly as sort_upsweep_kernel would.
-template <uint32_t BITS>
-__global__ __launch_bounds__(256) void morton_hist_kernel(uint32_t* __restrict__ codes, uint32_t* __restrict__ values,
+template <uint32_t BITS, uint32_t NT>
+__global__ __launch_bounds__(NT) void morton_hist_kernel(uint32_t* __restrict__ codes, uint32_t* __restrict__ values,
                                                           const float* __restrict__ f, const int* __restrict__ aabb,
                                                           uint32_t n, uint32_t nparts, int* __restrict__ aabb_out,
                                                           uint32_t* __restrict__ hist, uint32_t num_tiles)
@@ -177,15 +177,15 @@ __global__ __launch_bounds__(256) void morton_hist_kernel(uint32_t* __restrict__
     __shared__ uint32_t h[RADIX];
     __shared__ int sbox[6];
     float bmin[3], bmax[3];
-    for (uint32_t d = threadIdx.x; d < RADIX; d += 256) h[d] = 0;
+    for (uint32_t d = threadIdx.x; d < RADIX; d += NT) h[d] = 0;
     fold_scene_box(aabb, nparts, sbox, bmin, bmax);   // (its barriers also order the zeroing of h)
     if (aabb_out && blockIdx.x == 0 && threadIdx.x < 6) aabb_out[threadIdx.x] = sbox[threadIdx.x];
     const uint32_t tile = blockIdx.x, base = tile * kSortTile;
     const int lane = threadIdx.x & 63;
     const float minx = bmin[0], miny = bmin[1], minz = bmin[2], maxx = bmax[0], maxy = bmax[1], maxz = bmax[2];
 #pragma unroll 4
-    for (uint32_t i = 0; i < kSortItems; i++) {
-        const uint32_t gid = base + i * kSortThreads + threadIdx.x;
+    for (uint32_t i = 0; i < kSortTile / NT; i++) {
+        const uint32_t gid = base + i * NT + threadIdx.x;
         const bool valid = gid < n;
         uint32_t code = 0;
         if (valid) {
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void morton_hist_kernel(uint32_t* __restrict__
         }
     }
     __syncthreads();
-    for (uint32_t d = threadIdx.x; d < RADIX; d += 256) hist[(size_t)d * num_tiles + tile] = h[d];
+    for (uint32_t d = threadIdx.x; d < RADIX; d += NT) hist[(size_t)d * num_tiles + tile] = h[d];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -372,10 +372,11 @@ hipError_t launch_morton_hist(uint32_t* codes, uint32_t* values, const rt_triang
     if (n == 0) return hipSuccess;
     const uint32_t tiles = sort_num_tiles(n);
     const float* f = reinterpret_cast<const float*>(tris);
+    // few tiles (the 3 x 10-bit regime): 1024 threads per tile (4 triangles each) -- a pass over 245 tiles is one workgroup's chain
     if (bits == 10)
-        morton_hist_kernel<10><<<tiles, 256, 0, st>>>(codes, values, f, aabb, n, nparts ? nparts : 1u, aabb_out, hist, tiles);
+        morton_hist_kernel<10, 1024><<<tiles, 1024, 0, st>>>(codes, values, f, aabb, n, nparts ? nparts : 1u, aabb_out, hist, tiles);
     else
-        morton_hist_kernel<8><<<tiles, 256, 0, st>>>(codes, values, f, aabb, n, nparts ? nparts : 1u, aabb_out, hist, tiles);
+        morton_hist_kernel<8, 256><<<tiles, 256, 0, st>>>(codes, values, f, aabb, n, nparts ? nparts : 1u, aabb_out, hist, tiles);
     return hipGetLastError();
 }
 

@@ -16,31 +16,32 @@
 
 namespace rt {
 
-template <uint32_t BITS>
-__global__ __launch_bounds__(256) void sort_upsweep_kernel(const uint32_t* __restrict__ keys, uint32_t n,
+template <uint32_t BITS, uint32_t NT>
+__global__ __launch_bounds__(NT) void sort_upsweep_kernel(const uint32_t* __restrict__ keys, uint32_t n,
                                                            uint32_t shift, uint32_t num_tiles,
                                                            uint32_t* __restrict__ hist, const uint32_t* n_dev)
 {
     constexpr uint32_t RADIX = 1u << BITS;
     if (n_dev) n = *n_dev;   // device-side count (--pairs): tiles past it see no valid key and publish zeros
     __shared__ uint32_t h[RADIX];
-    for (uint32_t d = threadIdx.x; d < RADIX; d += 256) h[d] = 0;
+    for (uint32_t d = threadIdx.x; d < RADIX; d += NT) h[d] = 0;
     __syncthreads();
     const uint32_t tile = blockIdx.x;
     const uint32_t base = tile * kSortTile;
     const int lane = threadIdx.x & 63;
-    uint32_t k[kSortItems];
+    constexpr uint32_t ITEMS = kSortTile / NT;
+    uint32_t k[ITEMS];
 #pragma unroll
-    for (int i = 0; i < (int)kSortItems; i++) {
-        uint32_t idx = base + i * kSortThreads + threadIdx.x;
+    for (uint32_t i = 0; i < ITEMS; i++) {
+        uint32_t idx = base + i * NT + threadIdx.x;
         k[i] = idx < n ? keys[idx] : 0u;
     }
     // the tile histogram only needs counts, not ranks.  Spread digits: one LDS atomic per key.  Clustered digits
     // (sorted, flat or constant input -- lanes would queue on one LDS word): group the lanes with ballots and let
     // each group's leader add its size.  The wave chooses by looking at how many lanes share the first lane's digit.
 #pragma unroll
-    for (int i = 0; i < (int)kSortItems; i++) {
-        uint32_t idx = base + i * kSortThreads + threadIdx.x;
+    for (uint32_t i = 0; i < ITEMS; i++) {
+        uint32_t idx = base + i * NT + threadIdx.x;
         const bool valid = idx < n;
         const uint32_t d = (k[i] >> shift) & (RADIX - 1);
         const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void sort_upsweep_kernel(const uint32_t* __res
         }
     }
     __syncthreads();
-    for (uint32_t d = threadIdx.x; d < RADIX; d += 256)
+    for (uint32_t d = threadIdx.x; d < RADIX; d += NT)
         hist[(size_t)d * num_tiles + tile] = h[d];   // no global atomics anywhere in the sort
 }
 
@@ -236,7 +237,10 @@ static void radix_pass(const uint32_t* sk, const uint32_t* sv, uint32_t* dk, uin
                        uint32_t tiles, uint32_t* hist, uint32_t* offs, uint32_t* dt, hipStream_t st, const uint32_t* n_dev,
                        bool have_hist = false)
 {
-    if (!have_hist) sort_upsweep_kernel<BITS><<<tiles, kSortThreads, 0, st>>>(sk, n, shift, tiles, hist, n_dev);
+    if (!have_hist) {
+        if (tiles <= 512) sort_upsweep_kernel<BITS, 1024><<<tiles, 1024, 0, st>>>(sk, n, shift, tiles, hist, n_dev);   // few tiles: 4 keys per thread
+        else sort_upsweep_kernel<BITS, kSortThreads><<<tiles, kSortThreads, 0, st>>>(sk, n, shift, tiles, hist, n_dev);
+    }
     if (tiles <= 512) sort_scan_kernel<<<(1u << BITS) / 4, 256, 0, st>>>(hist, tiles, offs, dt);
     else sort_scan_wide_kernel<<<1u << BITS, 256, 0, st>>>(hist, tiles, offs, dt);
     // 512 threads per tile (8 keys each): half the ranking rounds of the 256-thread form and fewer registers (more waves
