@@ -373,3 +373,36 @@ def test_lbvh_level_and_sort_boundaries(rt, scenes, ora, n):
         torch.cuda.synchronize()
         op = ora.build_pairs(tris)
         assert_nodes_equal(rt.to_host(inp.nodes_out, rt.NODE, op["nodes"].shape[0]), op["nodes"], f"pairs n = {n}")
+
+
+def test_lbvh_handoff_under_concurrent_load(rt, scenes, ora):
+    """The upper-level hand-off (write-through records, ticket, acquire by the last arriver) while the GPU is busy with
+    something else: trace launches of another scene run on four other streams during every rebuild, so workgroups of the
+    build are dispatched unevenly, share CUs (and their L1s) with foreign waves and find the caches full of other data.
+    Every Node word and every leaf byte of 10 rebuilds (two alternating scenes, same buffers) against the oracle."""
+    import torch
+    from helpers import assert_nodes_equal
+    load_tris = scenes.grid_mesh(200, 3)
+    load = rt.BuildInput.allocate(load_tris)
+    rt.RunBottomUpBuild(load)
+    cam_d = rt.to_device(scenes.camera_a(200))
+    frames = [torch.zeros(1280 * 720 * 4, dtype=torch.uint8, device="cuda") for _ in range(4)]
+    side = [torch.cuda.Stream() for _ in range(4)]
+    sets = [scenes.soup(300000, 31, dup_fraction=0.2), scenes.grid_mesh(388, 8)[:300000]]
+    n = 300000
+    oracles = [ora.build_bvh(t) for t in sets]
+    inp = rt.BuildInput.allocate(sets[0])
+    main = torch.cuda.current_stream()
+    torch.cuda.synchronize()
+    for it in range(10):
+        k = it & 1
+        inp.triangles_in.copy_(rt.to_device(sets[k]))
+        for s_, fr in zip(side, frames):
+            s_.wait_stream(main)
+            with torch.cuda.stream(s_):
+                for _ in range(3):
+                    rt.Trace(load.triangles_out, load.nodes_out, fr, (1280, 720), cam_d, 0, 2)
+        rt.RunBottomUpBuild(inp)                      # on the main stream, concurrently with the 12 trace launches
+        torch.cuda.synchronize()
+        assert_nodes_equal(rt.to_host(inp.nodes_out, rt.NODE, 2 * (n - 1)), oracles[k]["nodes"], f"iteration {it}")
+        assert rt.to_host(inp.triangles_out, rt.TRIANGLE_PAIR, n).tobytes() == oracles[k]["leaves"].tobytes()
