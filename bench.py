@@ -370,6 +370,42 @@ def main():
     else:
         serial_ms_max = serial_ms
 
+    # ---- N > 1 diagnostics (outside the timed region): one frame at a time -- this rank's launch, then the gather alone
+    # (events on the launch stream; the gather's time is rank 0's view of the whole collective).  They tell a reader of a
+    # scaling record where a step's time goes: the slowest rank's part, or the collection on rank 0.
+    diag = None
+    if world > 1:
+        tr, ga = [], []
+        for _ in range(6):
+            dist.barrier()
+            torch.cuda.synchronize()
+            e0, e1, e2 = ev(), ev(), ev()
+            e0.record()
+            if strips:
+                trace_strips(compact[0], cam, args.render_type)
+            else:
+                trace_band(frames[0], cam, args.render_type)
+            e1.record()
+            if strips:
+                h = sharding.gather_strips(compact[0], staging[0], world, rank, dist, async_op=True)
+            else:
+                h = sharding.gather_bands(frames[0], W, H, world, rank, dist, async_op=True)
+            if h is not None:
+                h.wait()
+            if strips and rank == 0:
+                sharding.deinterleave(staging[0], frames[0], W, H, world)
+            e2.record()
+            e2.synchronize()
+            tr.append(e0.elapsed_time(e1))
+            ga.append(e1.elapsed_time(e2))
+        mine = torch.tensor([statistics.median(tr[1:]), statistics.median(ga[1:])], dtype=torch.float64, device=ctl_dev)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        diag = {"serial_trace_ms_per_rank": [round(float(v[0]), 4) for v in allv],
+                "serial_gather_ms_per_rank": [round(float(v[1]), 4) for v in allv],
+                "is": "one frame at a time after a barrier: each rank's trace launch, then the gather (+ de-interleave on rank 0) "
+                      "as seen from that rank; the timed region overlaps these across frames"}
+
     extras = {}
     if not args.no_extras:
         extras = {
@@ -500,7 +536,7 @@ def main():
                                       + (f" + one {'RCCL' if backend == 'nccl' else backend + ' (host-staged)'} gather to rank 0 per frame" if world > 1 else "")},
             "ranks": {"world_size": (dist.get_world_size() if use_dist else 1), "backend": backend if use_dist else None,
                       "gpus_visible": ndev, "self_launched": os.environ.get("RT_BENCH_SELF_LAUNCHED") == "1",
-                      "partition": partition if world > 1 else None, "band_costs_ms": band_costs,
+                      "partition": partition if world > 1 else None, "band_costs_ms": band_costs, "diagnostics": diag,
                       "note": (None if backend == "nccl" or world == 1 else
                                f"REHEARSAL: {world} ranks share {ndev} GPU(s), collectives over gloo with host staging -- "
                                "exercises the N > 1 control flow, not a scaling measurement")},
