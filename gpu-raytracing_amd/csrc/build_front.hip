@@ -17,9 +17,19 @@ namespace rt {
 // that rotated frame and un-rotated once at the end.  Everything is folded in the ordered-int
 // domain (DeviceUtils.cuh:3-13), wave-reduced, block-reduced through LDS and finished with 6 integer
 // atomics per BLOCK (exact, order independent).
+// Build mode (init.status != null): the kernel is the FIRST launch of rt_run_bottom_up_build and also does the build's
+// tiny initialisations (status words, the level hand-off counters: BuildWrapper.cu:288-303 does such things with six
+// memset / memcpy calls), and every workgroup STORES its partial box at aabb[6 * blockIdx.x] (no atomics, so nothing
+// needs resetting first); the Morton kernels fold the gridDim.x partial boxes.
+struct BuildInit { uint32_t* status; uint32_t n_tris; uint32_t* arrive; uint32_t arrive_words; };
+
 __global__ __launch_bounds__(1024) void scene_aabb_kernel(const float* __restrict__ f, uint64_t nfloats,
-                                                          int* __restrict__ aabb, uint32_t nparts)
+                                                          int* __restrict__ aabb, uint32_t nparts, BuildInit init)
 {
+    if (init.status && blockIdx.x == 0) {
+        if (threadIdx.x < 8) init.status[threadIdx.x] = threadIdx.x == 1 ? init.n_tris : 0u;   // [1] = number of leaves (pairs: overwritten)
+        for (uint32_t i = threadIdx.x; i < init.arrive_words; i += 1024) init.arrive[i] = 0u;
+    }
     const uint64_t nvec = nfloats >> 2;
     const uint64_t stride = (uint64_t)gridDim.x * 1024;
     uint64_t q = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
@@ -72,8 +82,12 @@ __global__ __launch_bounds__(1024) void scene_aabb_kernel(const float* __restric
         for (int w = 1; w < 16; w++) v = k < 3 ? min(v, red[w][k]) : max(v, red[w][k]);
         // 6 atomics per workgroup into partial box (blockIdx mod nparts): same-address device atomics queue at about
         // 50 ns each, so the build spreads them over kAabbParts copies that the Morton kernel folds
-        int* dst = aabb + 6 * (blockIdx.x % nparts);
-        if (k < 3) atomicMin(&dst[k], v); else atomicMax(&dst[k], v);
+        if (init.status) {
+            aabb[6 * blockIdx.x + k] = v;                       // build mode: this workgroup's own slot
+        } else {
+            int* dst = aabb + 6 * (blockIdx.x % nparts);
+            if (k < 3) atomicMin(&dst[k], v); else atomicMax(&dst[k], v);
+        }
     }
 }
 
@@ -107,10 +121,17 @@ __device__ __forceinline__ void fold_scene_box(const int* __restrict__ parts, ui
 {
     if (threadIdx.x < 6) sbox[threadIdx.x] = threadIdx.x < 3 ? 0x7f7fffff : (int)0x80800000;
     __syncthreads();
-    if (threadIdx.x < nparts * 6) {
-        const int v = parts[threadIdx.x];
+    // thread t (of the first 6 * (blockDim / 6)) folds word t % 6 of the partial boxes t / 6, t / 6 + blockDim / 6, ... in a
+    // register (consecutive threads read consecutive words), then ONE LDS atomic per thread
+    const uint32_t per = blockDim.x / 6;
+    if (threadIdx.x < per * 6) {
         const uint32_t k = threadIdx.x % 6;
-        if (k < 3) atomicMin(&sbox[k], v); else atomicMax(&sbox[k], v);
+        int acc = k < 3 ? 0x7f7fffff : (int)0x80800000;
+        for (uint32_t q = threadIdx.x / 6; q < nparts; q += per) {
+            const int v = parts[q * 6 + k];
+            acc = k < 3 ? min(acc, v) : max(acc, v);
+        }
+        if (k < 3) atomicMin(&sbox[k], acc); else atomicMax(&sbox[k], acc);
     }
     __syncthreads();
     for (int k = 0; k < 3; k++) { mn[k] = ordered_int_to_float(sbox[k]); mx[k] = ordered_int_to_float(sbox[3 + k]); }
@@ -342,18 +363,33 @@ hipError_t launch_reset_aabb(int* aabb, hipStream_t st)
     return hipGetLastError();
 }
 
+static uint32_t scene_aabb_blocks(uint32_t n, bool many)
+{
+    const uint64_t nfloats = (uint64_t)n * 9;
+    // ~4 float4 per thread.  One box (atomics on the same words from every workgroup): at most 255 workgroups of 1024.
+    // Separate partial boxes: twice the workgroups pay off.
+    uint64_t want = (nfloats / 16 + 1023) / 1024;
+    const uint32_t cap = many ? 510u : 255u;
+    uint32_t blocks = (uint32_t)(want < 3 ? 3 : (want > cap ? cap : want));
+    return blocks / 3 * 3;                                   // multiple of 3 (see kernel comment)
+}
+
 hipError_t launch_scene_aabb(const rt_triangle* tris, uint32_t n, int* aabb, hipStream_t st, uint32_t nparts)
 {
     if (n == 0) return hipSuccess;
-    const uint64_t nfloats = (uint64_t)n * 9;
-    // ~4 float4 per thread.  One box (nparts = 1): at most 255 workgroups of 1024, because the 6 final atomics of every
-    // workgroup hit the same words.  nparts partial boxes (each `aabb + 6 * i`, reset by the caller, folded by the
-    // consumer): the chains are nparts times shorter, so twice the workgroups pay off.
-    uint64_t want = (nfloats / 16 + 1023) / 1024;
-    const uint32_t cap = nparts > 1 ? 510u : 255u;
-    uint32_t blocks = (uint32_t)(want < 3 ? 3 : (want > cap ? cap : want));
-    blocks = blocks / 3 * 3;                                 // multiple of 3 (see kernel comment)
-    scene_aabb_kernel<<<blocks, 1024, 0, st>>>(reinterpret_cast<const float*>(tris), nfloats, aabb, nparts ? nparts : 1u);
+    scene_aabb_kernel<<<scene_aabb_blocks(n, nparts > 1), 1024, 0, st>>>(reinterpret_cast<const float*>(tris), (uint64_t)n * 9, aabb,
+                                                                        nparts ? nparts : 1u, BuildInit{nullptr, 0, nullptr, 0});
+    return hipGetLastError();
+}
+
+// the build's first launch: partial boxes stored at aabb_parts[6 * workgroup] (*nparts_out of them) + the initialisations
+hipError_t launch_scene_aabb_build(const rt_triangle* tris, uint32_t n, int* aabb_parts, uint32_t* nparts_out, uint32_t* status,
+                                   uint32_t* arrive, uint32_t arrive_words, hipStream_t st)
+{
+    const uint32_t blocks = scene_aabb_blocks(n, true);
+    *nparts_out = blocks;
+    scene_aabb_kernel<<<blocks, 1024, 0, st>>>(reinterpret_cast<const float*>(tris), (uint64_t)n * 9, aabb_parts, blocks,
+                                               BuildInit{status, n, arrive, arrive_words});
     return hipGetLastError();
 }
 

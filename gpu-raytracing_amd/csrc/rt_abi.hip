@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void build_init_kernel(uint32_t* status, int* 
     if (blockIdx.x != 0) return;
     if (threadIdx.x < 8) status[threadIdx.x] = threadIdx.x == 1 ? n : 0;   // [1] = number of leaves (pairs: overwritten)
     if (threadIdx.x < 6) aabb[threadIdx.x] = threadIdx.x < 3 ? 0x7f7fffff : (int)0x80800000;
-    for (uint32_t i = threadIdx.x; i < kAabbParts * 6; i += blockDim.x) aabb_parts[i] = (i % 6) < 3 ? 0x7f7fffff : (int)0x80800000;
+    for (uint32_t i = threadIdx.x; i < 6; i += blockDim.x) aabb_parts[i] = (i % 6) < 3 ? 0x7f7fffff : (int)0x80800000;
 }
 
 }  // namespace rt
@@ -124,11 +124,16 @@ int rt_run_bottom_up_build(const rt_build_input* input, const rt_arguments* args
     int* aabb_parts = reinterpret_cast<int*>(s + L.aabb_parts);
     const LevelPlan lp = lbvh_level_plan(n);
     const uint32_t arrive_words = (uint32_t)(lp.arrive_bytes / 4);
-    const uint32_t init_blocks = arrive_words > 256 ? (arrive_words / 1024 < 64 ? arrive_words / 1024 + 1 : 64) : 1;
-    build_init_kernel<<<init_blocks, 256, 0, st>>>(status, p_aabb, aabb_parts, n,
-                                                   reinterpret_cast<uint32_t*>(s + L.levels + lp.arrive_off), arrive_words);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = launch_scene_aabb(input->triangles_in, n, aabb_parts, st, kAabbParts);
+    uint32_t* arrive = reinterpret_cast<uint32_t*>(s + L.levels + lp.arrive_off);
+    uint32_t nparts = 1;
+    hipError_t e;
+    if (n) {
+        // the first launch: scene bounds (partial boxes, folded by the Morton kernels) + the build's initialisations
+        e = launch_scene_aabb_build(input->triangles_in, n, aabb_parts, &nparts, status, arrive, arrive_words, st);
+    } else {
+        build_init_kernel<<<1, 256, 0, st>>>(status, p_aabb, aabb_parts, n, arrive, arrive_words);
+        e = hipGetLastError();
+    }
     // with --pairs the number of leaves L <= n is only known on the device (status[1]); the reference copies it
     // back to the host (BuildWrapper.cu:317-321, a sync) -- here the downstream kernels read it from memory and the
     // grids are sized for n
@@ -143,9 +148,9 @@ int rt_run_bottom_up_build(const rt_build_input* input, const rt_arguments* args
     if (e == hipSuccess) {
         if (pairs)
             e = launch_morton_pairs(code_dst, value_dst, input->triangles_in, aabb_parts, n, reinterpret_cast<uint8_t*>(s + L.pair_flags),
-                                    reinterpret_cast<uint32_t*>(s + L.pair_sums), num_leaves, st, kAabbParts, p_aabb);
+                                    reinterpret_cast<uint32_t*>(s + L.pair_sums), num_leaves, st, nparts, p_aabb);
         else
-            e = launch_morton_hist(code_dst, value_dst, input->triangles_in, aabb_parts, n, st, kAabbParts, p_aabb,
+            e = launch_morton_hist(code_dst, value_dst, input->triangles_in, aabb_parts, n, st, nparts, p_aabb,
                                    sort_hist_table(s + L.sort, n), three ? 10 : 8);
     }
     if (e == hipSuccess) e = launch_radix_sort(morton, sorted, tmpk, tmpv, n, s + L.sort, st, n_dev, three ? 30 : 32, !pairs);

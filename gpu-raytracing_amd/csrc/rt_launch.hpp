@@ -85,7 +85,7 @@ struct BuLayout {
     size_t hybrid;          // hybrid top-tree work area
     size_t pair_flags;      // uint8[(n+1)/2] merge decision per candidate (--pairs)
     size_t pair_sums;       // uint32[ceil((n+1)/2 / 256)] leaf counts / offsets per workgroup (--pairs)
-    size_t aabb_parts;      // int32[kAabbParts][6] partial scene boxes
+    size_t aabb_parts;      // int32[kAabbParts][6] partial scene boxes (one per workgroup of the scene-box kernel)
     size_t total;
 };
 BuLayout bu_layout(uint32_t n);
@@ -104,8 +104,12 @@ SahLayout sah_layout(uint32_t n);
 hipError_t launch_reset_aabb(int* aabb, hipStream_t st);
 // scene box: `aabb` holds nparts ordered-int boxes (6 ints each, reset to empty by the caller); workgroup b folds into box
 // b mod nparts.  The Morton kernels fold the nparts boxes and (aabb_out != null) publish the result.
-constexpr uint32_t kAabbParts = 32;
+constexpr uint32_t kAabbParts = 510;   // at most this many partial boxes (one per workgroup of the build's scene-box kernel)
 hipError_t launch_scene_aabb(const rt_triangle* tris, uint32_t n, int* aabb, hipStream_t st, uint32_t nparts = 1);
+// the build's first launch (n > 0): partial boxes by plain stores, *nparts_out of them, + status words and the LBVH level
+// hand-off counters zeroed
+hipError_t launch_scene_aabb_build(const rt_triangle* tris, uint32_t n, int* aabb_parts, uint32_t* nparts_out, uint32_t* status,
+                                   uint32_t* arrive, uint32_t arrive_words, hipStream_t st);
 hipError_t launch_morton(uint32_t* codes, uint32_t* values, const rt_triangle* tris, const int* aabb, uint32_t n,
                          hipStream_t st, uint32_t nparts = 1, int* aabb_out = nullptr);
 // the same codes / values plus the first sort pass's tile histograms (digit = low `bits` bits, bits = 8 or 10) in one
