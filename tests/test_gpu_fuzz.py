@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 def _scene(rng, scenes):
     kind = rng.integers(0, 6)
-    n = int(rng.choice([3, 7, 63, 64, 65, 257, 1023, 1024, 1025, 2049, 4097, 5000, 12345, 40000]))
+    n = int(rng.choice([3, 7, 63, 64, 65, 257, 511, 513, 1023, 1024, 1025, 2049, 4097, 5000, 12345, 32769, 40000, 70001, 262145]))
     if kind == 0:
         return scenes.soup(n, int(rng.integers(1, 1000)), dup_fraction=float(rng.choice([0.0, 0.25, 0.9])),
                            size=float(rng.choice([0.002, 0.02, 0.3])))
