@@ -84,3 +84,31 @@ def test_bench_one_rank_rccl_api():
         assert d["ranks"]["backend"] == "nccl" and d["ranks"]["world_size"] == 1
         assert d["cpu_baseline"]["parity"]["gpu_frame_rows_equal_oracle"] is True
         assert d["cpu_baseline"]["parity"]["sum_box_tri_tests_equal_oracle"] is True
+
+
+def test_bench_line_schema():
+    """The one JSON line of `python bench.py` (N = 1, a small workload): every field of the driver's contract plus the
+    roofline and cpu_baseline objects, and the parity verdict the CPU-baseline leg attaches."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--grid", "120",
+                        "--width", "640", "--height", "360"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "serial_mrays", "build_ms"):
+        assert k in d, k
+    assert d["unit"] == "Mrays/s" and d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "l1" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample", "parity"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["parity"]["gpu_frame_rows_equal_oracle"] is True
+    assert c["parity"]["sum_box_tri_tests_equal_oracle"] is True
+    assert abs(d["value"] - 640 * 360 * 6 / (d["ms_per_step"] * 6 * 1e-3) / 1e6) / d["value"] < 0.01
