@@ -45,6 +45,26 @@
 
 namespace rt {
 
+#ifdef RT_LBVH_TIMING
+// `make TIMING=1`: thread 0 of every workgroup leaves 100 MHz timestamps at the phase boundaries (tools/lbvh_phases.py)
+constexpr uint32_t kStampBlocks = 32768, kStampSlots = 24;
+__device__ unsigned long long g_stamp[2][kStampBlocks * kStampSlots];
+#define RT_STAMP(arr, k) do { if (threadIdx.x == 0 && blockIdx.x < kStampBlocks) g_stamp[arr][blockIdx.x * kStampSlots + (k)] = wall_clock64(); } while (0)
+#endif
+#if defined(RT_LBVH_TIMING) && RT_LBVH_TIMING >= 2
+// TIMING=2: also the longest climb (merges done by one thread) of each pass (one global atomic per thread: perturbs the times)
+#define RT_STEPS_DECL uint32_t rt_steps = 0
+#define RT_STEPS_INC rt_steps++
+#define RT_STEPS_OUT(arr, k) do { if (blockIdx.x < kStampBlocks) atomicMax(&g_stamp[arr][blockIdx.x * kStampSlots + (k)], (unsigned long long)rt_steps); } while (0)
+#else
+#define RT_STEPS_DECL do { } while (0)
+#define RT_STEPS_INC do { } while (0)
+#define RT_STEPS_OUT(arr, k) do { } while (0)
+#endif
+#ifndef RT_LBVH_TIMING
+#define RT_STAMP(arr, k) do { } while (0)
+#endif
+
 constexpr uint32_t kLockEmpty = 0xFFFFFFFFu;
 constexpr uint32_t kLockDone = 0xFFFFFFFEu;
 constexpr uint32_t kCap = kUpperCap;  // segments an upper pass handles in LDS (the leaf pass: kLeafCap leaves)
@@ -68,6 +88,7 @@ struct LevelArgs {
     rt_triangle_pair* leaves;
     rt_node* nodes;
     uint32_t* status;
+    uint32_t* sink;              // 16 dwords nobody reads (see the merge step)
     // per level k: blocks[k] blocks; cnt[k][block] open roots, rec[k][block][kMaxOpen][kRecDwords] their records;
     // arrive[k][block] (k >= 1) tickets taken by the level k-1 blocks that feed it (zero before the launch);
     // sub_cnt / sub_rec [k][block][kUpperFan / kSubFan] scratch of the fallback path
@@ -89,17 +110,22 @@ struct LevelCfgT {
     static constexpr uint32_t oDl = 0;                 // int   [CAP+1]  delta at boundary b
     static constexpr uint32_t oBnd = oDl + CAP + 4;    // int   [CAP+1]  last leaf left of boundary b (upper passes only)
     static constexpr uint32_t oLock = oBnd + (STAGE_ ? 0 : CAP + 4);  // u32   [CAP+1]
-    static constexpr uint32_t oRange = oLock + CAP + 4;  // u32 [CAP]  sf | sl << 15 | cc << 30
+    static constexpr uint32_t oRange = oLock + CAP + 4;  // u32 [CAP]  sf:11 | sl:11 | cc:2 | (delta at the far end + 1):7
     static constexpr uint32_t oDesc = oRange + CAP;
     static constexpr uint32_t oBox = oDesc + CAP;      // float [6][CAP]
-    static constexpr uint32_t oWs = oBox + 6 * CAP;    // scan workspace [0, 32), hand-off flag [32], prefix table [40, 40 + 65)
+    static constexpr uint32_t oAbs = oBox + 6 * CAP;   // u32 [CAP]  upper passes: the leaf index at the segment's far end
+    static constexpr uint32_t oWs = oAbs + (STAGE_ ? 0 : CAP);    // scan workspace [0, 32), hand-off flag [32], prefix table [40, 40 + 65)
     static constexpr uint32_t oStage = oWs + 40 + kUpperFan + 8;   // leaf pass only: the block's node pairs, 16 dwords each
+    static constexpr uint32_t oSink = oWs + 40;   // leaf pass only (it has no prefix table): 16 dwords nobody reads
     static constexpr uint32_t kDwords = oStage + (STAGE_ ? 16 * CAP : 0);
     static constexpr size_t kBytes = (size_t)kDwords * 4;
 };
 typedef LevelCfgT<kLeafCap, kLeafThreads, true> LeafCfg;   // 52.5 KB of LDS (32 KB of it the node staging area): three 512-thread workgroups per CU
 typedef LevelCfgT<kCap, 1024, false> UpperCfg;             // 90 KB: the upper levels run a handful of workgroups
-static_assert(3 * LeafCfg::kBytes <= 160 * 1024, "three leaf workgroups per CU");
+// LDS is handed out in 1280-byte granules (160 KB / 128): 42 granules per leaf workgroup, 3 x 42 <= 128 -- 64 bytes more
+// and only two fit (measured: the kernel's run time went up by 15 % although every workgroup was faster)
+static_assert((LeafCfg::kBytes + 1279) / 1280 * 3 <= 128, "three leaf workgroups per CU");
+static_assert(kCap <= 2048, "a deposited range packs two 11-bit segment indices");
 
 // Hand-off stores: write-through at agent scope (`sc1`), so that the records a workgroup leaves for the next level are
 // in memory once its `s_waitcnt vmcnt(0)` returns -- without an L2 write-back per workgroup (an agent-scope release
@@ -130,9 +156,11 @@ __device__ __forceinline__ int delta_adjacent(const uint32_t* __restrict__ codes
 // emit what stays open to (out_cnt, out_rec).  All 1024 threads of the workgroup call it together.
 template <bool LEAF>
 __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, uint32_t n, uint32_t B0, uint32_t S,
-                                           const uint32_t* src_rec, uint32_t* out_cnt, uint32_t* out_rec)
+                                           const uint32_t* src_rec, uint32_t* out_cnt, uint32_t* out_rec, uint32_t so = 0)
 {
     using C = typename std::conditional<LEAF, LeafCfg, UpperCfg>::type;
+    (void)so;
+    RT_STAMP(LEAF ? 0 : 1, so);
     constexpr uint32_t NT = C::NT;
     int* dl = reinterpret_cast<int*>(smem + C::oDl);
     int* bnd = reinterpret_cast<int*>(smem + C::oBnd);
@@ -140,6 +168,7 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
     uint32_t* s_range = smem + C::oRange;
     uint32_t* s_desc = smem + C::oDesc;
     float* s_box = reinterpret_cast<float*>(smem + C::oBox);
+    uint32_t* s_abs = smem + C::oAbs;
     uint32_t* ws = smem + C::oWs;            // [0..17) scan scratch
     const uint32_t* pref = smem + C::oWs + 40;  // [0..64] prefix of the source blocks' counts (upper passes)
     const uint32_t tid = threadIdx.x;
@@ -159,6 +188,7 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
     // a wave store costs per lane whatever its width: profiles/r02_ta_microbench.txt).
     // dword 7 (w28 of slot 0: child | type, never 0 for a real slot) doubles as the "pair was completed here" marker.
     uint32_t* stage = smem + C::oStage;
+    uint32_t* sink = LEAF ? smem + C::oSink : a.sink;
     if (LEAF) {
         for (uint32_t j = tid; j < C::CAP; j += NT) stage[j * 16 + 7] = 0u;
     }
@@ -178,9 +208,11 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
         }
     }
     __syncthreads();
+    RT_STAMP(LEAF ? 0 : 1, so + 1);
 
     for (uint32_t s0 = tid; s0 < S; s0 += NT) {
         uint32_t sf = s0, sl = s0, desc, cc;
+        uint32_t fabs = 0, labs = 0;   // upper passes: first / last leaf under this segment
         float bx[6];
         if (LEAF) {
             // GenerateTriangles (BottomUpBuilder.cu:287-312) fused: gather the triangle, emit the
@@ -233,91 +265,116 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
             const uint4 r0 = reinterpret_cast<const uint4*>(r)[0];
             const uint4 r1 = reinterpret_cast<const uint4*>(r)[1];
             const uint4 r2 = reinterpret_cast<const uint4*>(r)[2];
+            fabs = r0.x;
+            labs = r0.y;
             desc = r0.z;
             cc = r0.w;
             bx[0] = __uint_as_float(r1.x); bx[1] = __uint_as_float(r1.y); bx[2] = __uint_as_float(r1.z);
             bx[3] = __uint_as_float(r1.w); bx[4] = __uint_as_float(r2.x); bx[5] = __uint_as_float(r2.y);
         }
 
+        // The climb is a chain of dependent LDS round trips (one workgroup's whole pass lasts as long as its deepest
+        // path), so a step makes only two: deposit + exchange, then the sibling's state.  Everything else a step needs
+        // travels in registers or in the deposit: the deltas at the two ends of the range (the far one is part of the
+        // deposit), and in the upper passes the leaf indices at the two ends.
+        int ldl = dl[sf], rdl = dl[sl + 1];
+        RT_STEPS_DECL;
         while (true) {
-            const int ldl = dl[sf], rdl = dl[sl + 1];
             if (ldl < 0 && rdl < 0) break;  // covers every leaf: the finished root
-            const bool go_right = ldl < rdl;  // I am the LEFT child of my parent
-            const uint32_t b = go_right ? sl + 1 : sf;
+            // go_right (ldl < rdl): I am the LEFT child of my parent.  As a mask, so that what depends on it is bit
+            // selects and not the compiler's if / else (deltas lie in [-1, 63]: the difference cannot overflow)
+            const uint32_t gm = (uint32_t)((ldl - rdl) >> 31);
+            auto pick = [gm](uint32_t right, uint32_t left) { return left ^ ((right ^ left) & gm); };  // go_right ? right : left
+            const uint32_t b = pick(sl + 1, sf);
+            const int far = min(ldl, rdl);
 
-            s_range[s0] = sf | (sl << 15) | (cc << 30);
+            s_range[s0] = sf | (sl << 11) | (cc << 22) | ((uint32_t)(far + 1) << 24);
             s_desc[s0] = desc;
 #pragma unroll
             for (int k = 0; k < 6; k++) s_box[k * C::CAP + s0] = bx[k];
-            // my state is in LDS before the exchange makes me findable (one wave's DS ops retire in order)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (!LEAF) s_abs[s0] = pick(fabs, labs);
+            // my state is in LDS before the exchange makes me findable: the DS operations of one wave are performed in
+            // issue order, so the compiler must keep the order and the hardware does
+            asm volatile("" ::: "memory");
             const uint32_t other = atomicExch(&lock[b], s0);
             asm volatile("" ::: "memory");
             if (other == kLockEmpty) break;  // first at the rendezvous: the sibling will carry on
             lock[b] = kLockDone;
+            RT_STEPS_INC;
 
             const uint32_t orange = s_range[other];
-            const uint32_t odesc = s_desc[other], occ = orange >> 30;
+            const uint32_t odesc = s_desc[other], occ = (orange >> 22) & 3u;
+            const uint32_t oabs = LEAF ? 0u : s_abs[other];
+            const int ofar = (int)(orange >> 24) - 1;
             float ob[6];
 #pragma unroll
             for (int k = 0; k < 6; k++) ob[k] = s_box[k * C::CAP + other];
 
-            // left / right child of the new node
-            uint32_t Lsf, Rsl, Ldesc, Rdesc, Lcc, Rcc;
-            float Lb[6], Rb[6];
-            if (go_right) {
-                Lsf = sf; Rsl = (orange >> 15) & 0x7FFFu; Ldesc = desc; Rdesc = odesc; Lcc = cc; Rcc = occ;
-#pragma unroll
-                for (int k = 0; k < 6; k++) { Lb[k] = bx[k]; Rb[k] = ob[k]; }
-            } else {
-                Lsf = orange & 0x7FFFu; Rsl = sl; Ldesc = odesc; Rdesc = desc; Lcc = occ; Rcc = cc;
-#pragma unroll
-                for (int k = 0; k < 6; k++) { Lb[k] = ob[k]; Rb[k] = bx[k]; }
-            }
-            const int pl = dl[Lsf], pr = dl[Rsl + 1];
-            const bool is_root = pl < 0 && pr < 0;
-            const uint32_t fP = LEAF ? B0 + Lsf : (uint32_t)(bnd[Lsf] + 1);
-            const uint32_t lP = LEAF ? B0 + Rsl : (uint32_t)bnd[Rsl + 1];
-            const uint32_t idx = is_root ? 0u : (pl < pr ? lP : fP);  // Karras index of the new node
+            // The new node's pair = [left child: box, descriptor][right child: box, descriptor].  I am the left child iff
+            // go_right, so "mine" and "the sibling's" go to slot my / slot 1 - my: selects on addresses, not on the
+            // fourteen values (the climb is bound by the instructions on its dependent chain).
+            const uint32_t osf = orange & 0x7FFu, osl = (orange >> 11) & 0x7FFu;
+            const uint32_t my = gm + 1u;
+            const bool is_root = (far & ofar) < 0;       // the deltas at both ends of the merged range are -1: node 0
+            // the merged range's end deltas are (far, ofar) in my direction's order (never equal below the root: the
+            // codes inside the range agree on more bits than either delta); a LEFT child iff the left one is smaller
+            const uint32_t lm = (uint32_t)((far - ofar) >> 31) ^ ~gm;   // all ones: left child -> index = last leaf
+            const uint32_t nsf = pick(sf, osf), nsl = pick(osl, sl);
+            const uint32_t fP = LEAF ? B0 + nsf : pick(fabs, oabs);
+            const uint32_t lP = LEAF ? B0 + nsl : pick(oabs, labs);
+            const uint32_t idx = is_root ? 0u : (fP ^ ((lP ^ fP) & lm));  // Karras index of the new node
 
-            const bool Lbox = (Ldesc >> 29) == RT_CHILD_BOX, Rbox = (Rdesc >> 29) == RT_CHILD_BOX;
-            // the new node's pair: box + descriptor of each child; then parent:29|count:3 of the children's own pairs
-            // (BottomUpBuilder.cu:204-213, :265, :282).  Leaf pass: into the staging area (the children's pairs were
-            // completed in this block too); upper passes: straight to memory (few nodes, indices anywhere).
+            const bool mbox = (desc >> 29) == RT_CHILD_BOX, obox = (odesc >> 29) == RT_CHILD_BOX;
+            // the new node's pair, then parent:29|count:3 of the children's own pairs (BottomUpBuilder.cu:204-213, :265,
+            // :282).  Leaf pass: into the staging area (the children's pairs were completed in this block too); upper
+            // passes: straight to memory (few nodes, indices anywhere).
             uint32_t* nw = LEAF ? stage + (idx - B0) * 16 : reinterpret_cast<uint32_t*>(a.nodes + (size_t)idx * 2);
-            uint32_t* cl = LEAF ? stage + ((Ldesc & kIndexMask) / 2 - B0) * 16 : reinterpret_cast<uint32_t*>(a.nodes + (Ldesc & kIndexMask));
-            uint32_t* cr = LEAF ? stage + ((Rdesc & kIndexMask) / 2 - B0) * 16 : reinterpret_cast<uint32_t*>(a.nodes + (Rdesc & kIndexMask));
-            nw[0] = __float_as_uint(Lb[0]); nw[1] = __float_as_uint(Lb[1]); nw[2] = __float_as_uint(Lb[2]);
-            *reinterpret_cast<uint4*>(nw + 4) =
-                make_uint4(__float_as_uint(Lb[3]), __float_as_uint(Lb[4]), __float_as_uint(Lb[5]), Ldesc);
-            nw[8] = __float_as_uint(Rb[0]); nw[9] = __float_as_uint(Rb[1]); nw[10] = __float_as_uint(Rb[2]);
-            *reinterpret_cast<uint4*>(nw + 12) =
-                make_uint4(__float_as_uint(Rb[3]), __float_as_uint(Rb[4]), __float_as_uint(Rb[5]), Rdesc);
-            if (is_root) {  // Q3: the reference leaves the root pair's parent undefined; defined as 0
-                nw[3] = (Lbox ? 2u : 1u) << 29;
-                nw[11] = (Rbox ? 2u : 1u) << 29;
+            uint32_t* nm = nw + my * 8;
+            uint32_t* no = nw + 8 - my * 8;
+            nm[0] = __float_as_uint(bx[0]); nm[1] = __float_as_uint(bx[1]); nm[2] = __float_as_uint(bx[2]);
+            *reinterpret_cast<uint4*>(nm + 4) = make_uint4(__float_as_uint(bx[3]), __float_as_uint(bx[4]), __float_as_uint(bx[5]), desc);
+            no[0] = __float_as_uint(ob[0]); no[1] = __float_as_uint(ob[1]); no[2] = __float_as_uint(ob[2]);
+            *reinterpret_cast<uint4*>(no + 4) = make_uint4(__float_as_uint(ob[3]), __float_as_uint(ob[4]), __float_as_uint(ob[5]), odesc);
+            // The step is straight-line code: with a few lanes of one wave on the critical path every taken branch is
+            // an instruction-fetch round trip nobody hides, so the stores that only a box child needs go to a sink
+            // when the child is a leaf, and the root's own parent words are written after the loop.
+            {
+                uint32_t* cb = LEAF ? stage + ((desc & kIndexMask) / 2 - B0) * 16 : reinterpret_cast<uint32_t*>(a.nodes + (desc & kIndexMask));
+                uint32_t* c = mbox ? cb : sink;
+                c[3] = (idx * 2 + my) | (((cc & 1u) ? 2u : 1u) << 29);
+                c[11] = (idx * 2 + my) | (((cc & 2u) ? 2u : 1u) << 29);
             }
-            if (Lbox) {
-                cl[3] = (idx * 2) | (((Lcc & 1u) ? 2u : 1u) << 29);
-                cl[11] = (idx * 2) | (((Lcc & 2u) ? 2u : 1u) << 29);
-            }
-            if (Rbox) {
-                cr[3] = (idx * 2 + 1) | (((Rcc & 1u) ? 2u : 1u) << 29);
-                cr[11] = (idx * 2 + 1) | (((Rcc & 2u) ? 2u : 1u) << 29);
+            {
+                uint32_t* cb = LEAF ? stage + ((odesc & kIndexMask) / 2 - B0) * 16 : reinterpret_cast<uint32_t*>(a.nodes + (odesc & kIndexMask));
+                uint32_t* c = obox ? cb : sink;
+                c[3] = (idx * 2 + 1 - my) | (((occ & 1u) ? 2u : 1u) << 29);
+                c[11] = (idx * 2 + 1 - my) | (((occ & 2u) ? 2u : 1u) << 29);
             }
 
-            sf = Lsf;
-            sl = Rsl;
+            sf = nsf;
+            sl = nsl;
+            ldl = (int)pick((uint32_t)ldl, (uint32_t)ofar);
+            rdl = (int)pick((uint32_t)ofar, (uint32_t)rdl);
+            fabs = fP;
+            labs = lP;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                bx[k] = fminf(Lb[k], Rb[k]);
-                bx[3 + k] = fmaxf(Lb[3 + k], Rb[3 + k]);
+                bx[k] = fminf(bx[k], ob[k]);
+                bx[3 + k] = fmaxf(bx[3 + k], ob[3 + k]);
             }
             desc = ((idx * 2) & kIndexMask) | ((uint32_t)RT_CHILD_BOX << 29);
-            cc = (Lbox ? 1u : 0u) | (Rbox ? 2u : 0u);
+            cc = (mbox ? 1u << my : 0u) | (obox ? 2u >> my : 0u);
+        }
+        RT_STEPS_OUT(LEAF ? 0 : 1, LEAF ? 5 : 21 + so / 7);
+        if ((ldl & rdl) < 0 && (desc >> 29) == RT_CHILD_BOX) {
+            // this thread completed the root.  Q3: the reference leaves the root pair's parent undefined; defined as 0
+            uint32_t* nw = LEAF ? stage : reinterpret_cast<uint32_t*>(a.nodes);
+            nw[3] = ((cc & 1u) ? 2u : 1u) << 29;
+            nw[11] = ((cc & 2u) ? 2u : 1u) << 29;
         }
     }
     __syncthreads();
+    RT_STAMP(LEAF ? 0 : 1, so + 2);
 
     if (LEAF) {
         // the completed pairs of this block, 16 bytes per lane, consecutive lanes on consecutive addresses.  A pair whose
@@ -332,6 +389,7 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
         }
     }
 
+    RT_STAMP(LEAF ? 0 : 1, so + 3);
     // open roots = rendezvous points where only one child ever arrived, in boundary (= leaf) order
     uint32_t ids[C::PER];
     uint32_t mine = 0;
@@ -350,11 +408,11 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
         if (id < kLockDone) {
             if (pos < kMaxOpen) {
                 const uint32_t rg = s_range[id];
-                const uint32_t osf = rg & 0x7FFFu, osl = (rg >> 15) & 0x7FFFu;
+                const uint32_t osf = rg & 0x7FFu, osl = (rg >> 11) & 0x7FFu;
                 const uint32_t f = LEAF ? B0 + osf : (uint32_t)(bnd[osf] + 1);
                 const uint32_t l = LEAF ? B0 + osl : (uint32_t)bnd[osl + 1];
                 uint4* o = reinterpret_cast<uint4*>(out_rec + (size_t)pos * kRecDwords);
-                store_sc1(o + 0, f, l, s_desc[id], rg >> 30);
+                store_sc1(o + 0, f, l, s_desc[id], (rg >> 22) & 3u);
                 store_sc1(o + 1, __float_as_uint(s_box[0 * C::CAP + id]), __float_as_uint(s_box[1 * C::CAP + id]),
                           __float_as_uint(s_box[2 * C::CAP + id]), __float_as_uint(s_box[3 * C::CAP + id]));
                 store_sc1(o + 2, __float_as_uint(s_box[4 * C::CAP + id]), __float_as_uint(s_box[5 * C::CAP + id]),
@@ -368,6 +426,7 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
         if (total > kMaxOpen) atomicOr(a.status, 1u);  // cannot happen: <= 2 * depth(62) open roots
     }
     __syncthreads();   // LDS is reused by the next pass of this workgroup
+    RT_STAMP(LEAF ? 0 : 1, so + 4);
 }
 
 // prefix table of the open-root counts of `nb` (<= 64) source blocks -> pref[0..64] in LDS; returns their sum
@@ -407,6 +466,7 @@ __global__ __launch_bounds__(1024) void lbvh_upper_kernel(LevelArgs a)
     const uint32_t tid = threadIdx.x;
     const uint32_t n = a.n_dev ? *a.n_dev : a.n;
     uint32_t blk = blockIdx.x;
+    RT_STAMP(1, 0);
 
     for (uint32_t lvl = 1; lvl < a.num_levels; lvl++) {
         if (lvl > 1) {
@@ -427,6 +487,7 @@ __global__ __launch_bounds__(1024) void lbvh_upper_kernel(LevelArgs a)
                 *flag = last ? 1u : 0u;
             }
             __syncthreads();
+            RT_STAMP(1, 1 + (lvl - 1) * 7 - 1);
             if (*flag == 0) return;
             blk = grp;
         }
@@ -437,8 +498,9 @@ __global__ __launch_bounds__(1024) void lbvh_upper_kernel(LevelArgs a)
         uint32_t* out_cnt = a.cnt[lvl] + blk;
         uint32_t* out_rec = a.rec[lvl] + (size_t)blk * kMaxOpen * kRecDwords;
         const uint32_t S = load_prefix(smem, src_cnt, nb);
+        RT_STAMP(1, 1 + (lvl - 1) * 7);
         if (S <= RT_LBVH_FAST_CAP) {
-            level_pass<false>(a, smem, n, 0, S, src_rec, out_cnt, out_rec);
+            level_pass<false>(a, smem, n, 0, S, src_rec, out_cnt, out_rec, 2 + (lvl - 1) * 7);
         } else {
             // more open roots than one pass holds (deep trees: long runs of equal codes): kSubFan source blocks at a
             // time (always fit: kSubFan * kMaxOpen <= CAP) into this block's scratch, then one pass over those results
@@ -492,6 +554,7 @@ LevelPlan lbvh_level_plan(uint32_t n)
     uint32_t blocks = (n + kLeafCap - 1) / kLeafCap;
     if (blocks == 0) blocks = 1;
     // the arrival counters of all levels first, contiguous: the build's init kernel zeroes [arrive_off, +arrive_bytes)
+    p.sink_off = take(64);
     p.arrive_off = off;
     {
         uint32_t b = blocks;
@@ -545,6 +608,7 @@ hipError_t launch_lbvh_levels(const rt_triangle* tris, const uint32_t* codes, co
         a.leaves = leaves;
         a.nodes = nodes;
         a.status = status;
+        a.sink = reinterpret_cast<uint32_t*>(base + p.sink_off);
         a.num_levels = p.num_levels;
         for (uint32_t k = 0; k < kMaxLevels; k++) {
             const bool on = k < p.num_levels;
@@ -565,3 +629,18 @@ hipError_t launch_lbvh_levels(const rt_triangle* tris, const uint32_t* codes, co
 }
 
 }  // namespace rt
+
+#ifdef RT_LBVH_TIMING
+extern "C" __attribute__((visibility("default"))) int rt_debug_lbvh_stamps(unsigned long long* out, int arr)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rt::g_stamp), sizeof(unsigned long long) * rt::kStampBlocks * rt::kStampSlots,
+                                    (size_t)arr * sizeof(unsigned long long) * rt::kStampBlocks * rt::kStampSlots);
+}
+extern "C" __attribute__((visibility("default"))) int rt_debug_lbvh_stamps_clear()
+{
+    void* p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(rt::g_stamp));
+    if (e != hipSuccess) return (int)e;
+    return (int)hipMemset(p, 0, sizeof(unsigned long long) * 2 * rt::kStampBlocks * rt::kStampSlots);
+}
+#endif

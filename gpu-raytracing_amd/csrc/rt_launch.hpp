@@ -68,6 +68,7 @@ struct LevelPlan {
     size_t sub_cnt_off[kMaxLevels];  // fallback scratch of the upper levels
     size_t sub_rec_off[kMaxLevels];
     size_t arrive_off, arrive_bytes; // all arrival counters, contiguous: must be zero when the build kernel starts
+    size_t sink_off;                 // 64 bytes nobody reads: where the upper passes' predicated-off stores land
     size_t total;
 };
 LevelPlan lbvh_level_plan(uint32_t n);

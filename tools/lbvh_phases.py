@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Where the LBVH hierarchy kernels spend their time: per-phase timestamps of every workgroup.
+
+Needs the timing build of the library (cd gpu-raytracing_amd/csrc && make clean && make TIMING=1), which is never the
+shipped one.  python3 tools/lbvh_phases.py [G]   (G = grid size of the bench mesh, 708 -> 1,002,528 triangles)"""
+import ctypes, importlib, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+rt = importlib.import_module("gpu-raytracing_amd")
+scenes = importlib.import_module("gpu-raytracing_amd.scenes")
+G = int(sys.argv[1]) if len(sys.argv) > 1 else 708
+L = rt.lib()
+BLOCKS, SLOTS = 32768, 24
+inp = rt.BuildInput.allocate(scenes.grid_mesh(G, 1))
+for _ in range(3):
+    rt.RunBottomUpBuild(inp)
+torch.cuda.synchronize()
+assert L.rt_debug_lbvh_stamps_clear() == 0
+rt.RunBottomUpBuild(inp)
+torch.cuda.synchronize()
+
+
+def stamps(arr):
+    buf = np.zeros(BLOCKS * SLOTS, dtype=np.uint64)
+    assert L.rt_debug_lbvh_stamps(buf.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong)), arr) == 0
+    return buf.reshape(BLOCKS, SLOTS).astype(np.int64)
+
+
+def us(x):
+    return x / 100.0   # 100 MHz
+
+
+leaf = stamps(0)
+used = leaf[:, 0] > 0
+t = leaf[used]
+t0 = t[:, 0].min()
+print(f"n = {inp.num_triangles}; leaf kernel: {used.sum()} workgroups, first start -> last end {us(t[:, 4].max() - t0):.2f} us")
+names = ["init (deltas, locks)", "gather + leaf + climb", "node sweep", "open roots out"]
+for k, nm in enumerate(names):
+    d = us(t[:, k + 1] - t[:, k])
+    print(f"  {nm:24s} avg {d.mean():7.2f}  min {d.min():7.2f}  max {d.max():7.2f} us")
+d = us(t[:, 4] - t[:, 0])
+print(f"  {'workgroup total':24s} avg {d.mean():7.2f}  min {d.min():7.2f}  max {d.max():7.2f} us")
+print(f"  longest climb of a workgroup (merges by one thread): avg {t[:, 5].mean():.1f}  max {t[:, 5].max()}")
+st = np.sort(us(t[:, 0] - t0))
+print("  start times (us) percentiles 0/25/50/75/100:", [round(float(np.percentile(st, q)), 2) for q in (0, 25, 50, 75, 100)])
+
+up = stamps(1)
+used = up[:, 0] > 0
+t = up[used]
+steps = t[:, 21:24].copy()
+t = t[:, :21]
+t0 = t[:, 0].min()
+print(f"upper kernel: {used.sum()} workgroups; first start -> last stamp {us(t.max() - t0):.2f} us")
+lab = ["entry", "L1 prefix", "L1 pass entry", "L1 init", "L1 climb", "L1 (no sweep)", "L1 records out",
+       "L2 ticket", "L2 prefix", "L2 pass entry", "L2 init", "L2 climb", "L2 -", "L2 records out",
+       "L3 ticket", "L3 prefix", "L3 pass entry", "L3 init", "L3 climb", "L3 -", "L3 records out"]
+for k, nm in enumerate(lab):
+    col = t[:, k]
+    ok = col > 0
+    if ok.any():
+        v = us(col[ok] - t0)
+        print(f"  {nm:16s} reached by {ok.sum():4d}: at avg {v.mean():7.2f}  min {v.min():7.2f}  max {v.max():7.2f} us after the first workgroup's start")
+for k in range(3):
+    ok = steps[:, k] > 0
+    if ok.any():
+        print(f"  L{k + 1} longest climb (merges by one thread): avg {steps[ok, k].mean():.1f}  max {steps[ok, k].max()}  ({ok.sum()} workgroups)")
