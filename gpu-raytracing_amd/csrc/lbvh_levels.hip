@@ -132,15 +132,21 @@ static_assert(kCap <= 2048, "a deposited range packs two 11-bit segment indices"
 // fence = buffer_wbl2 flushes every dirty line of the XCD's L2, i.e. the leaves and nodes everybody is streaming out:
 // measured 2.3x on the 10M build).  MI355X_MICROARCH.md, inter-workgroup visibility: sc1 stores, drained, then the
 // ticket; the last arriver acquires before its workgroup reads.
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// They are relaxed agent-scope atomic stores (the compiler emits global_store_dwordx2 / dword ... sc1).  The same stores
+// written as inline asm (one global_store_dwordx4 ... sc1 per 16 bytes) were corrupted under load: the compiler reused
+// the data registers of an asm store for the next record word right after it, and one word of a record then carried the
+// value of the word stored next from the same register (z of the box = the delta stored 16 bytes later; found by
+// tests/test_gpu_parity.py::test_lbvh_handoff_under_concurrent_load after a change of register allocation: 103 of
+// 1500 builds wrong with the asm stores, 0 of 3000 with these).  The compiler handles the hazards of its own stores.
 __device__ __forceinline__ void store_sc1(uint4* p, uint32_t x, uint32_t y, uint32_t z, uint32_t w)
 {
-    const u32x4 v = {x, y, z, w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+    __hip_atomic_store(q, (unsigned long long)x | ((unsigned long long)y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, (unsigned long long)z | ((unsigned long long)w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void store_sc1(uint32_t* p, uint32_t v)
 {
-    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ int delta_adjacent(const uint32_t* __restrict__ codes, int g, uint32_t n)

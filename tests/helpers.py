@@ -56,4 +56,5 @@ def assert_nodes_equal(got: np.ndarray, exp: np.ndarray, what=""):
         assert bad.size == 0, f"{what}: {f} differs at {bad[:8]} got {got[f][bad[:4]]} exp {exp[f][bad[:4]]} ({bad.size} slots)"
     for f in ("min", "max"):
         bad = np.nonzero((got[f] != exp[f]).any(axis=1))[0]
-        assert bad.size == 0, f"{what}: {f} differs at {bad[:8]} ({bad.size} slots)"
+        assert bad.size == 0, (f"{what}: {f} differs at {bad[:8]} ({bad.size} slots); got {got[f][bad[:4]].tolist()} "
+                               f"exp {exp[f][bad[:4]].tolist()} w28 {[hex(int(x)) for x in got['w28'][bad[:4]]]}")

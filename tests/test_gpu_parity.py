@@ -406,3 +406,41 @@ def test_lbvh_handoff_under_concurrent_load(rt, scenes, ora):
         torch.cuda.synchronize()
         assert_nodes_equal(rt.to_host(inp.nodes_out, rt.NODE, 2 * (n - 1)), oracles[k]["nodes"], f"iteration {it}")
         assert rt.to_host(inp.triangles_out, rt.TRIANGLE_PAIR, n).tobytes() == oracles[k]["leaves"].tobytes()
+
+
+def test_lbvh_build_stress_back_to_back(rt, scenes, ora):
+    """600 rebuilds of two alternating scenes into the same buffers without a host synchronisation in between, two out of
+    three with trace launches of another scene in flight on four side streams, every Node byte compared on the GPU.
+    This is the test that exposes a hand-off store whose data registers are reused too early (csrc/lbvh_levels.hip,
+    store_sc1): with such stores about 7 % of these builds carried a wrong box word; the single-build tests passed."""
+    import torch
+    n = 300000
+    load = rt.BuildInput.allocate(scenes.grid_mesh(200, 3))
+    rt.RunBottomUpBuild(load)
+    cam_d = rt.to_device(scenes.camera_a(200))
+    frames = [torch.zeros(1280 * 720 * 4, dtype=torch.uint8, device="cuda") for _ in range(4)]
+    side = [torch.cuda.Stream() for _ in range(4)]
+    sets = [scenes.soup(n, 31, dup_fraction=0.2), scenes.grid_mesh(388, 8)[:n]]
+    oracles = [ora.build_bvh(t) for t in sets]
+    dsets = [rt.to_device(s) for s in sets]
+    exp_nodes = [torch.from_numpy(o["nodes"].view(np.uint8).reshape(-1).copy()).cuda() for o in oracles]
+    exp_leaves = [torch.from_numpy(o["leaves"].view(np.uint8).reshape(-1).copy()).cuda() for o in oracles]
+    inp = rt.BuildInput.allocate(sets[0])
+    main = torch.cuda.current_stream()
+    bad = torch.zeros(1, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    for it in range(600):
+        k = it & 1
+        inp.triangles_in.copy_(dsets[k])
+        if it % 3 != 2:
+            for s_, fr in zip(side, frames):
+                s_.wait_stream(main)
+                with torch.cuda.stream(s_):
+                    for _ in range(3):
+                        rt.Trace(load.triangles_out, load.nodes_out, fr, (1280, 720), cam_d, 0, 2)
+        rt.RunBottomUpBuild(inp)
+        got_n = inp.nodes_out.view(torch.uint8).reshape(-1)[: exp_nodes[k].numel()]
+        got_l = inp.triangles_out.view(torch.uint8).reshape(-1)[: exp_leaves[k].numel()]
+        bad += (got_n != exp_nodes[k]).any().to(torch.int64) + (got_l != exp_leaves[k]).any().to(torch.int64)
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0, f"{int(bad.item())} of 600 builds differ from the oracle"
