@@ -46,20 +46,11 @@
 namespace rt {
 
 #ifdef RT_LBVH_TIMING
-// `make TIMING=1`: thread 0 of every workgroup leaves 100 MHz timestamps at the phase boundaries (tools/lbvh_phases.py)
+// librt_amd_timing.so (see the Makefile): thread 0 of every workgroup leaves 100 MHz timestamps at the phase boundaries
+// (tools/lbvh_phases.py)
 constexpr uint32_t kStampBlocks = 32768, kStampSlots = 24;
 __device__ unsigned long long g_stamp[2][kStampBlocks * kStampSlots];
 #define RT_STAMP(arr, k) do { if (threadIdx.x == 0 && blockIdx.x < kStampBlocks) g_stamp[arr][blockIdx.x * kStampSlots + (k)] = wall_clock64(); } while (0)
-#endif
-#if defined(RT_LBVH_TIMING) && RT_LBVH_TIMING >= 2
-// TIMING=2: also the longest climb (merges done by one thread) of each pass (one global atomic per thread: perturbs the times)
-#define RT_STEPS_DECL uint32_t rt_steps = 0
-#define RT_STEPS_INC rt_steps++
-#define RT_STEPS_OUT(arr, k) do { if (blockIdx.x < kStampBlocks) atomicMax(&g_stamp[arr][blockIdx.x * kStampSlots + (k)], (unsigned long long)rt_steps); } while (0)
-#else
-#define RT_STEPS_DECL do { } while (0)
-#define RT_STEPS_INC do { } while (0)
-#define RT_STEPS_OUT(arr, k) do { } while (0)
 #endif
 #ifndef RT_LBVH_TIMING
 #define RT_STAMP(arr, k) do { } while (0)
@@ -284,7 +275,6 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
         // travels in registers or in the deposit: the deltas at the two ends of the range (the far one is part of the
         // deposit), and in the upper passes the leaf indices at the two ends.
         int ldl = dl[sf], rdl = dl[sl + 1];
-        RT_STEPS_DECL;
         while (true) {
             if (ldl < 0 && rdl < 0) break;  // covers every leaf: the finished root
             // go_right (ldl < rdl): I am the LEFT child of my parent.  As a mask, so that what depends on it is bit
@@ -306,7 +296,6 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
             asm volatile("" ::: "memory");
             if (other == kLockEmpty) break;  // first at the rendezvous: the sibling will carry on
             lock[b] = kLockDone;
-            RT_STEPS_INC;
 
             const uint32_t orange = s_range[other];
             const uint32_t odesc = s_desc[other], occ = (orange >> 22) & 3u;
@@ -371,7 +360,6 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
             desc = ((idx * 2) & kIndexMask) | ((uint32_t)RT_CHILD_BOX << 29);
             cc = (mbox ? 1u << my : 0u) | (obox ? 2u >> my : 0u);
         }
-        RT_STEPS_OUT(LEAF ? 0 : 1, LEAF ? 5 : 21 + so / 7);
         if ((ldl & rdl) < 0 && (desc >> 29) == RT_CHILD_BOX) {
             // this thread completed the root.  Q3: the reference leaves the root pair's parent undefined; defined as 0
             uint32_t* nw = LEAF ? stage : reinterpret_cast<uint32_t*>(a.nodes);

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Where the LBVH hierarchy kernels spend their time: per-phase timestamps of every workgroup.
 
-Needs the timing build of the library (cd gpu-raytracing_amd/csrc && make clean && make TIMING=1), which is never the
-shipped one.  python3 tools/lbvh_phases.py [G]   (G = grid size of the bench mesh, 708 -> 1,002,528 triangles)"""
+Uses the measurement variant of the library (cd gpu-raytracing_amd/csrc && make librt_amd_timing.so), never the shipped
+one.  python3 tools/lbvh_phases.py [G]   (G = grid size of the bench mesh, 708 -> 1,002,528 triangles)"""
 import ctypes, importlib, os, sys
 import numpy as np
 import torch
@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 rt = importlib.import_module("gpu-raytracing_amd")
 scenes = importlib.import_module("gpu-raytracing_amd.scenes")
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 708
+rt.LIB_PATH = os.path.join(os.path.dirname(rt.LIB_PATH), "librt_amd_timing.so")
 L = rt.lib()
 BLOCKS, SLOTS = 32768, 24
 inp = rt.BuildInput.allocate(scenes.grid_mesh(G, 1))
@@ -42,14 +43,12 @@ for k, nm in enumerate(names):
     print(f"  {nm:24s} avg {d.mean():7.2f}  min {d.min():7.2f}  max {d.max():7.2f} us")
 d = us(t[:, 4] - t[:, 0])
 print(f"  {'workgroup total':24s} avg {d.mean():7.2f}  min {d.min():7.2f}  max {d.max():7.2f} us")
-print(f"  longest climb of a workgroup (merges by one thread): avg {t[:, 5].mean():.1f}  max {t[:, 5].max()}")
 st = np.sort(us(t[:, 0] - t0))
 print("  start times (us) percentiles 0/25/50/75/100:", [round(float(np.percentile(st, q)), 2) for q in (0, 25, 50, 75, 100)])
 
 up = stamps(1)
 used = up[:, 0] > 0
 t = up[used]
-steps = t[:, 21:24].copy()
 t = t[:, :21]
 t0 = t[:, 0].min()
 print(f"upper kernel: {used.sum()} workgroups; first start -> last stamp {us(t.max() - t0):.2f} us")
@@ -62,7 +61,3 @@ for k, nm in enumerate(lab):
     if ok.any():
         v = us(col[ok] - t0)
         print(f"  {nm:16s} reached by {ok.sum():4d}: at avg {v.mean():7.2f}  min {v.min():7.2f}  max {v.max():7.2f} us after the first workgroup's start")
-for k in range(3):
-    ok = steps[:, k] > 0
-    if ok.any():
-        print(f"  L{k + 1} longest climb (merges by one thread): avg {steps[ok, k].mean():.1f}  max {steps[ok, k].max()}  ({ok.sum()} workgroups)")

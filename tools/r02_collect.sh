@@ -23,4 +23,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_build10m -- pyth
 python3 tools/kstats.py $O/prof_build10m > $O/build10m_kernel_stats.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_build1m -- python3 tools/build_loop.py 20 708 > $O/build1m.log 2>&1
 python3 tools/kstats.py $O/prof_build1m > $O/build1m_kernel_stats.txt
+timeout -k 10 200 python3 tools/lbvh_phases.py 708 > $O/lbvh_phases_1m.txt 2>&1
+timeout -k 10 200 python3 tools/lbvh_phases.py 2237 > $O/lbvh_phases_10m.txt 2>&1
+timeout -k 10 60 tools/bin/lds_latency > $O/lds_latency.txt 2>&1
+python3 bench.py --type bottom-up-pairs --steps 30 --warmup 5 --no-cpu-baseline > $O/bench_pairs.json 2>> $O/bench_default.err
+python3 bench.py --type sah-pairs --steps 30 --warmup 5 --no-cpu-baseline > $O/bench_sah_pairs.json 2>> $O/bench_default.err
+python3 bench.py --type hybrid --steps 30 --warmup 5 --no-cpu-baseline > $O/bench_hybrid.json 2>> $O/bench_default.err
 echo collected
