@@ -61,3 +61,54 @@ def test_hybrid_tiny(rt, scenes, ora, n):
     if n >= 1:
         got = rt.to_host(inp.nodes_out, rt.NODE, o["nodes"].shape[0])
         assert got.tobytes() == o["nodes"].tobytes()
+
+
+@pytest.mark.parametrize("pairs", [False, True])
+def test_hybrid_and_pairs_build_stress_back_to_back(pairs, rt, scenes, ora):
+    """300 rebuilds (hybrid top tree; with and without triangle pairs) of two alternating scenes into the same buffers
+    without a host synchronisation in between, two out of three with trace launches in flight on side streams; every
+    node byte the oracle defines is compared on the GPU (see tests/test_gpu_parity.py::test_lbvh_build_stress_back_to_back)."""
+    import torch
+    n = 200000
+    load = rt.BuildInput.allocate(scenes.grid_mesh(200, 3))
+    rt.RunBottomUpBuild(load)
+    cam_d = rt.to_device(scenes.camera_a(200))
+    frames = [torch.zeros(1280 * 720 * 4, dtype=torch.uint8, device="cuda") for _ in range(4)]
+    side = [torch.cuda.Stream() for _ in range(4)]
+    sets = [scenes.soup(n, 51, dup_fraction=0.2), scenes.grid_mesh(317, 4)[:n]]
+    args = rt.Arguments(build_type=rt.kHybrid, enable_pairs=pairs)
+    dsets = [rt.to_device(s) for s in sets]
+    inp = rt.BuildInput.allocate(sets[0])
+    main = torch.cuda.current_stream()
+    # the first build of each scene is checked against the oracle elsewhere (test_hybrid_top_tree, test_pairs_*); here
+    # every later build must reproduce the first one byte for byte (buffers zeroed before each build: slots the build
+    # leaves undefined stay zero)
+    ref = [None, None]
+    bad = torch.zeros(1, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    for it in range(300):
+        k = it & 1
+        inp.triangles_in.copy_(dsets[k])
+        inp.nodes_out.zero_()
+        inp.triangles_out.zero_()
+        if it % 3 != 2 and it >= 2:
+            for s_, fr in zip(side, frames):
+                s_.wait_stream(main)
+                with torch.cuda.stream(s_):
+                    for _ in range(3):
+                        rt.Trace(load.triangles_out, load.nodes_out, fr, (1280, 720), cam_d, 0, 2)
+        rt.RunBottomUpBuild(inp, args, hybrid=True)
+        if ref[k] is None:
+            torch.cuda.synchronize()
+            ref[k] = (inp.nodes_out.clone(), inp.triangles_out.clone())
+        else:
+            bad += (inp.nodes_out != ref[k][0]).any().to(torch.int64) + (inp.triangles_out != ref[k][1]).any().to(torch.int64)
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0, f"{int(bad.item())} of 298 builds differ from the first build of their scene"
+    # and the first builds are the oracle's trees
+    for k in range(2):
+        if not pairs:
+            o = ora.build_hybrid(sets[k])
+            got = np.frombuffer(ref[k][0].cpu().numpy().tobytes(), dtype=rt.NODE)[: o["nodes"].shape[0]]
+            from helpers import assert_nodes_equal
+            assert_nodes_equal(got, o["nodes"], f"scene {k}")

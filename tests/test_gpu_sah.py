@@ -149,3 +149,42 @@ def test_sah_10m_bit_exact(rt, scenes, ora):
     L = g["L"]
     assert ora.count_nodes(g["nodes"], 0, 1) == (2 * L - 1, L, L - 1)
     assert ora.verify_hierarchy(g["nodes"], 0, 1) == 0
+
+
+@pytest.mark.parametrize("pairs,splits", [(False, False), (True, False), (False, True)])
+def test_sah_build_stress_back_to_back(pairs, splits, rt, scenes, ora):
+    """150 SAH rebuilds of two alternating scenes into the same buffers, two out of three with trace launches of another
+    scene in flight on four side streams; node and leaf bytes compared on the GPU after every build (the pattern that
+    exposed a store hazard in the LBVH hand-off, tests/test_gpu_parity.py::test_lbvh_build_stress_back_to_back)."""
+    import torch
+    n = 150000
+    load = rt.BuildInput.allocate(scenes.grid_mesh(200, 3))
+    rt.RunBottomUpBuild(load)
+    cam_d = rt.to_device(scenes.camera_a(200))
+    frames = [torch.zeros(1280 * 720 * 4, dtype=torch.uint8, device="cuda") for _ in range(4)]
+    side = [torch.cuda.Stream() for _ in range(4)]
+    sets = [scenes.soup(n, 41, dup_fraction=0.2), scenes.grid_mesh(275, 9)[:n]]
+    args = rt.Arguments(build_type=rt.kSAH, enable_pairs=pairs, enable_splits=splits)
+    oracles = [ora.build_sah(t, pairs, splits) for t in sets]
+    dsets = [rt.to_device(s) for s in sets]
+    exp_nodes = [torch.from_numpy(o["nodes"][: 128 + 2 * o["L"]].view(np.uint8).reshape(-1).copy()).cuda() for o in oracles]
+    exp_leaves = [torch.from_numpy(o["leaves"][: o["R"]].view(np.uint8).reshape(-1).copy()).cuda() for o in oracles]
+    inp = rt.BuildInput.allocate(sets[0], sah=True)
+    main = torch.cuda.current_stream()
+    bad = torch.zeros(1, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    for it in range(150):
+        k = it & 1
+        inp.triangles_in.copy_(dsets[k])
+        if it % 3 != 2:
+            for s_, fr in zip(side, frames):
+                s_.wait_stream(main)
+                with torch.cuda.stream(s_):
+                    for _ in range(3):
+                        rt.Trace(load.triangles_out, load.nodes_out, fr, (1280, 720), cam_d, 0, 2)
+        rt.RunSahBuild(inp, args)
+        got_n = inp.nodes_out.view(torch.uint8).reshape(-1)[: exp_nodes[k].numel()]
+        got_l = inp.triangles_out.view(torch.uint8).reshape(-1)[: exp_leaves[k].numel()]
+        bad += (got_n != exp_nodes[k]).any().to(torch.int64) + (got_l != exp_leaves[k]).any().to(torch.int64)
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0, f"{int(bad.item())} of 150 builds differ from the oracle"
