@@ -439,6 +439,166 @@ __device__ __forceinline__ uint32_t load_prefix(uint32_t* smem, const uint32_t* 
     return pref[kUpperFan];
 }
 
+// ---- the LAST level by range searches instead of a climb.
+//
+// The climb of a pass is a chain of dependent merges as long as the deepest path of its tree (22 for the 310 open roots
+// the 1M build's last level folds, at about 0.85 us each: profiles/r02_lbvh_phases_1m.txt).  The last level has no such
+// need: every node it makes is complete, and a node of a radix tree is determined by its split alone -- the node that
+// splits at boundary b reaches, on either side, to the nearest boundary with a SMALLER delta (inside a node every other
+// boundary has a larger delta than its split, and the two ends have smaller ones).  So one thread per boundary finds its
+// node's range with two binary descents over a sparse table of delta minima, the boxes of its two children are two
+// range unions from a sparse table of boxes (min / max are exact and idempotent: two overlapping power-of-two windows),
+// and the Karras indices follow from the ranges as in the climb.  No dependence between nodes: 9 barrier-separated table
+// levels + two short phases instead of 22 dependent merges.  Same Node words as the climb (tests: every build whose
+// last level holds 2 .. 511 open roots takes this path).
+constexpr uint32_t kTopCap = 511;     // open roots the table method holds (boundaries 0 .. 511)
+constexpr uint32_t kTopLevels = 9;    // windows of 1 .. 256 entries
+struct TopCfg {
+    static constexpr uint32_t P = 512;
+    static constexpr uint32_t oBox = 0;                              // float [kTopLevels][6][P]
+    static constexpr uint32_t oDelta = oBox + kTopLevels * 6 * P;    // int   [kTopLevels][P + 4]  minima over boundaries
+    static constexpr uint32_t oF = oDelta + kTopLevels * (P + 4);    // u32 [P] first leaf of segment
+    static constexpr uint32_t oL = oF + P;                           // u32 [P] last leaf
+    static constexpr uint32_t oDesc = oL + P;
+    static constexpr uint32_t oCc = oDesc + P;
+    static constexpr uint32_t oIdx = oCc + P;                        // u32 [P] Karras index of the node that splits at boundary b
+    static constexpr uint32_t kDwords = oIdx + P;
+    static constexpr size_t kBytes = (size_t)kDwords * 4;
+};
+static_assert(TopCfg::kBytes <= 160 * 1024, "the tables of the last level fit the LDS of a CU");
+
+__device__ __forceinline__ void top_pass(const LevelArgs& a, uint32_t* smem, uint32_t S, const uint32_t* src_rec, uint32_t so = 0)
+{
+    using T = TopCfg;
+    (void)so;
+    RT_STAMP(1, so);
+    constexpr uint32_t P = T::P;
+    float* tb = reinterpret_cast<float*>(smem + T::oBox);
+    int* td = reinterpret_cast<int*>(smem + T::oDelta);
+    uint32_t* sg_f = smem + T::oF;
+    uint32_t* sg_l = smem + T::oL;
+    uint32_t* sg_desc = smem + T::oDesc;
+    uint32_t* sg_cc = smem + T::oCc;
+    uint32_t* nd_idx = smem + T::oIdx;
+    const uint32_t tid = threadIdx.x;
+    auto TB = [&](uint32_t k, uint32_t c, uint32_t i) -> float& { return tb[(k * 6 + c) * P + i]; };
+    auto TD = [&](uint32_t k, uint32_t i) -> int& { return td[k * (P + 4) + i]; };
+
+    // the records (the prefix table that locates them lives in LDS this pass is about to overwrite: registers first)
+    uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0;
+    if (tid < S) {
+        const uint32_t* pref = smem + UpperCfg::oWs + 40;
+        uint32_t pb = 0;
+#pragma unroll
+        for (uint32_t step = kUpperFan / 2; step; step >>= 1) pb += (pref[pb + step] <= tid) ? step : 0u;
+        const uint4* r = reinterpret_cast<const uint4*>(src_rec + ((size_t)pb * kMaxOpen + (tid - pref[pb])) * kRecDwords);
+        r0 = r[0]; r1 = r[1]; r2 = r[2];
+    }
+    __syncthreads();
+    if (tid < S) {
+        sg_f[tid] = r0.x; sg_l[tid] = r0.y; sg_desc[tid] = r0.z; sg_cc[tid] = r0.w;
+        TB(0, 0, tid) = __uint_as_float(r1.x); TB(0, 1, tid) = __uint_as_float(r1.y); TB(0, 2, tid) = __uint_as_float(r1.z);
+        TB(0, 3, tid) = __uint_as_float(r1.w); TB(0, 4, tid) = __uint_as_float(r2.x); TB(0, 5, tid) = __uint_as_float(r2.y);
+        TD(0, tid) = (int)r2.z;                       // boundary t = the left end of segment t
+        if (tid == S - 1) TD(0, S) = (int)r2.w;       // the last boundary = the right end of the last segment
+    }
+    __syncthreads();
+    // sparse tables: level k holds windows of 2^k entries starting at i
+#pragma unroll 1
+    for (uint32_t k = 1; k < kTopLevels; k++) {
+        const uint32_t w = 1u << k, h = w >> 1;
+        if (tid + w <= S) {
+#pragma unroll
+            for (uint32_t c = 0; c < 3; c++) {
+                TB(k, c, tid) = fminf(TB(k - 1, c, tid), TB(k - 1, c, tid + h));
+                TB(k, 3 + c, tid) = fmaxf(TB(k - 1, 3 + c, tid), TB(k - 1, 3 + c, tid + h));
+            }
+        }
+        if (tid + w <= S + 1) TD(k, tid) = min(TD(k - 1, tid), TD(k - 1, tid + h));
+        __syncthreads();
+    }
+
+    RT_STAMP(1, so + 1);   // records in, tables built
+    // ---- the node that splits at boundary b (1 <= b <= S-1): range, Karras index
+    const uint32_t b = tid;
+    const bool node = b >= 1 && b < S;
+    uint32_t sf = 0, sl = 0, idx = 0, Lj = 0, Rj = 0;
+    int pl = -1, pr = -1;
+    if (node) {
+        const int v = TD(0, b);
+        uint32_t pos = b;            // every boundary in [pos, b-1] has a larger delta than v
+#pragma unroll
+        for (int k = (int)kTopLevels - 1; k >= 0; k--) {
+            const uint32_t w = 1u << k;
+            if (pos >= w && TD((uint32_t)k, pos - w) > v) pos -= w;
+        }
+        uint32_t q = b + 1;          // every boundary in [b+1, q-1] has a larger delta than v
+#pragma unroll
+        for (int k = (int)kTopLevels - 1; k >= 0; k--) {
+            const uint32_t w = 1u << k;
+            if (q + w <= S + 1 && TD((uint32_t)k, q) > v) q += w;
+        }
+        if (pos == 0 || q > S) {
+            atomicOr(a.status, 1u);   // cannot happen at the last level: the outermost deltas are -1
+            pos = 1; q = S;
+        }
+        Lj = pos - 1; Rj = q;
+        sf = Lj; sl = Rj - 1;
+        pl = TD(0, Lj); pr = TD(0, Rj);
+        const bool is_root = (pl & pr) < 0;
+        idx = is_root ? 0u : (pl < pr ? sg_l[sl] : sg_f[sf]);   // a left child is numbered by its last leaf, a right child by its first
+        nd_idx[b] = idx;
+    }
+    __syncthreads();
+    if (node) {
+        auto range_box = [&](uint32_t s0, uint32_t s1, float* o) {
+            const uint32_t len = s1 - s0 + 1;
+            const uint32_t k = 31u - (uint32_t)__clz(len);
+            const uint32_t t1 = s1 + 1 - (1u << k);
+#pragma unroll
+            for (uint32_t c = 0; c < 3; c++) {
+                o[c] = fminf(TB(k, c, s0), TB(k, c, t1));
+                o[3 + c] = fmaxf(TB(k, 3 + c, s0), TB(k, 3 + c, t1));
+            }
+        };
+        // children: segments [sf, b-1] and [b, sl]; a single segment is the open root itself, else an internal node of this
+        // pass (left children are numbered by their last leaf, right children by their first)
+        const bool singleL = sf == b - 1, singleR = b == sl;
+        float bo[6], bp[6];
+        range_box(sf, b - 1, bo);
+        range_box(b, sl, bp);
+        const uint32_t dO = singleL ? sg_desc[sf] : (((sg_l[b - 1] * 2) & kIndexMask) | ((uint32_t)RT_CHILD_BOX << 29));
+        const uint32_t dP = singleR ? sg_desc[sl] : (((sg_f[b] * 2) & kIndexMask) | ((uint32_t)RT_CHILD_BOX << 29));
+        const bool boxO = (dO >> 29) == RT_CHILD_BOX, boxP = (dP >> 29) == RT_CHILD_BOX;
+        const bool is_root = (pl & pr) < 0;
+        uint32_t* nw = reinterpret_cast<uint32_t*>(a.nodes + (size_t)idx * 2);
+        // my own parent words: my parent splits at the end of my range that has the larger delta
+        const uint32_t side = pl < pr ? 0u : 1u;
+        const uint32_t pslot = is_root ? 0u : nd_idx[pl < pr ? Rj : Lj] * 2 + side;
+        *reinterpret_cast<uint4*>(nw + 0) = make_uint4(__float_as_uint(bo[0]), __float_as_uint(bo[1]), __float_as_uint(bo[2]), pslot | ((boxO ? 2u : 1u) << 29));
+        *reinterpret_cast<uint4*>(nw + 4) = make_uint4(__float_as_uint(bo[3]), __float_as_uint(bo[4]), __float_as_uint(bo[5]), dO);
+        *reinterpret_cast<uint4*>(nw + 8) = make_uint4(__float_as_uint(bp[0]), __float_as_uint(bp[1]), __float_as_uint(bp[2]), pslot | ((boxP ? 2u : 1u) << 29));
+        *reinterpret_cast<uint4*>(nw + 12) = make_uint4(__float_as_uint(bp[3]), __float_as_uint(bp[4]), __float_as_uint(bp[5]), dP);
+        // a child that is an open root of the level below: its pair exists already, its parent words are mine to write
+        if (singleL && boxO) {
+            uint32_t* c = reinterpret_cast<uint32_t*>(a.nodes + (dO & kIndexMask));
+            const uint32_t cc = sg_cc[sf];
+            c[3] = (idx * 2) | (((cc & 1u) ? 2u : 1u) << 29);
+            c[11] = (idx * 2) | (((cc & 2u) ? 2u : 1u) << 29);
+        }
+        if (singleR && boxP) {
+            uint32_t* c = reinterpret_cast<uint32_t*>(a.nodes + (dP & kIndexMask));
+            const uint32_t cc = sg_cc[sl];
+            c[3] = (idx * 2 + 1) | (((cc & 1u) ? 2u : 1u) << 29);
+            c[11] = (idx * 2 + 1) | (((cc & 2u) ? 2u : 1u) << 29);
+        }
+    }
+    __syncthreads();   // LDS is reused
+    RT_STAMP(1, so + 2);
+    RT_STAMP(1, so + 3);
+    RT_STAMP(1, so + 4);
+}
+
 // ---- level 0: one 512-thread workgroup per 512 leaves (grids are sized for the largest possible n)
 __global__ __launch_bounds__(kLeafThreads, 6) void lbvh_leaf_kernel(LevelArgs a)   // three workgroups per CU (LDS), 24 waves
 {
@@ -493,7 +653,10 @@ __global__ __launch_bounds__(1024) void lbvh_upper_kernel(LevelArgs a)
         uint32_t* out_rec = a.rec[lvl] + (size_t)blk * kMaxOpen * kRecDwords;
         const uint32_t S = load_prefix(smem, src_cnt, nb);
         RT_STAMP(1, 1 + (lvl - 1) * 7);
-        if (S <= RT_LBVH_FAST_CAP) {
+        // (the test variant of the library keeps the climb at the last level too: it exists to exercise the sub-pass path)
+        if (RT_LBVH_FAST_CAP == kCap && lvl + 1 == a.num_levels && S >= 2 && S <= kTopCap) {
+            top_pass(a, smem, S, src_rec, 2 + (lvl - 1) * 7);
+        } else if (S <= RT_LBVH_FAST_CAP) {
             level_pass<false>(a, smem, n, 0, S, src_rec, out_cnt, out_rec, 2 + (lvl - 1) * 7);
         } else {
             // more open roots than one pass holds (deep trees: long runs of equal codes): kSubFan source blocks at a
@@ -575,6 +738,8 @@ LevelPlan lbvh_level_plan(uint32_t n)
     return p;
 }
 
+constexpr size_t kUpperLds = UpperCfg::kBytes > TopCfg::kBytes ? UpperCfg::kBytes : TopCfg::kBytes;
+
 hipError_t launch_lbvh_levels(const rt_triangle* tris, const uint32_t* codes, const uint32_t* sorted_indices,
                               uint32_t n, rt_triangle_pair* leaves, rt_node* nodes, void* level_scratch,
                               uint32_t* status, hipStream_t st, const uint32_t* n_dev)
@@ -585,7 +750,7 @@ hipError_t launch_lbvh_levels(const rt_triangle* tris, const uint32_t* codes, co
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LeafCfg::kBytes);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lbvh_upper_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)UpperCfg::kBytes);
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kUpperLds);
         return e;
     });
     if (attr_err != hipSuccess) return attr_err;
@@ -616,7 +781,7 @@ hipError_t launch_lbvh_levels(const rt_triangle* tris, const uint32_t* codes, co
         // the arrival counters must be zero: the caller's init kernel clears them (rt_run_bottom_up_build), see
         // lbvh_arrive_region()
         lbvh_leaf_kernel<<<p.blocks[0], kLeafThreads, LeafCfg::kBytes, st>>>(a);
-        if (p.num_levels > 1) lbvh_upper_kernel<<<p.blocks[1], 1024, UpperCfg::kBytes, st>>>(a);
+        if (p.num_levels > 1) lbvh_upper_kernel<<<p.blocks[1], 1024, kUpperLds, st>>>(a);
     }
     if (n < 2 || n_dev) lbvh_tiny_kernel<<<1, 64, 0, st>>>(leaves, nodes, n, n_dev);
     return hipGetLastError();
