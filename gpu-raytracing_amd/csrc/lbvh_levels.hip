@@ -68,7 +68,8 @@ constexpr uint32_t kCap = kUpperCap;  // segments an upper pass handles in LDS (
 static_assert(RT_LBVH_FAST_CAP <= kCap, "one pass holds kCap segments");
 static_assert(kLeafCap <= kCap && kSubFan * kMaxOpen <= kCap && kUpperFan % kSubFan == 0 && kUpperFan / kSubFan * kMaxOpen <= kCap,
               "the fallback's sub-passes and its merging pass always fit one pass");
-static_assert(kUpperFan == 64, "pref[] is filled by one wave and searched in 6 steps");
+constexpr uint32_t kPrefSlots = 64;   // pref[]: filled by one wave, searched in 6 steps
+static_assert(kUpperFan <= kPrefSlots, "one prefix entry per source block");
 
 struct LevelArgs {
     const float* tris;           // 9 floats per triangle
@@ -106,7 +107,7 @@ struct LevelCfgT {
     static constexpr uint32_t oBox = oDesc + CAP;      // float [6][CAP]
     static constexpr uint32_t oAbs = oBox + 6 * CAP;   // u32 [CAP]  upper passes: the leaf index at the segment's far end
     static constexpr uint32_t oWs = oAbs + (STAGE_ ? 0 : CAP);    // scan workspace [0, 32), hand-off flag [32], prefix table [40, 40 + 65)
-    static constexpr uint32_t oStage = oWs + 40 + kUpperFan + 8;   // leaf pass only: the block's node pairs, 16 dwords each
+    static constexpr uint32_t oStage = oWs + 40 + kPrefSlots + 8;   // leaf pass only: the block's node pairs, 16 dwords each
     static constexpr uint32_t oSink = oWs + 40;   // leaf pass only (it has no prefix table): 16 dwords nobody reads
     static constexpr uint32_t kDwords = oStage + (STAGE_ ? 16 * CAP : 0);
     static constexpr size_t kBytes = (size_t)kDwords * 4;
@@ -174,7 +175,7 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
     auto rec_ptr = [&](uint32_t s) -> const uint32_t* {
         uint32_t pb = 0;
 #pragma unroll
-        for (uint32_t step = kUpperFan / 2; step; step >>= 1) pb += (pref[pb + step] <= s) ? step : 0u;
+        for (uint32_t step = kPrefSlots / 2; step; step >>= 1) pb += (pref[pb + step] <= s) ? step : 0u;
         return src_rec + ((size_t)pb * kMaxOpen + (s - pref[pb])) * kRecDwords;
     };
 
@@ -436,7 +437,7 @@ __device__ __forceinline__ uint32_t load_prefix(uint32_t* smem, const uint32_t* 
         if (tid == 0) pref[0] = 0;
     }
     __syncthreads();
-    return pref[kUpperFan];
+    return pref[kPrefSlots];
 }
 
 // ---- the LAST level by range searches instead of a climb.
@@ -451,29 +452,44 @@ __device__ __forceinline__ uint32_t load_prefix(uint32_t* smem, const uint32_t* 
 // and the Karras indices follow from the ranges as in the climb.  No dependence between nodes: 9 barrier-separated table
 // levels + two short phases instead of 22 dependent merges.  Same Node words as the climb (tests: every build whose
 // last level holds 2 .. 511 open roots takes this path).
-constexpr uint32_t kTopCap = 511;     // open roots the table method holds (boundaries 0 .. 511)
-constexpr uint32_t kTopLevels = 9;    // windows of 1 .. 256 entries
-struct TopCfg {
-    static constexpr uint32_t P = 512;
-    static constexpr uint32_t oBox = 0;                              // float [kTopLevels][6][P]
-    static constexpr uint32_t oDelta = oBox + kTopLevels * 6 * P;    // int   [kTopLevels][P + 4]  minima over boundaries
-    static constexpr uint32_t oF = oDelta + kTopLevels * (P + 4);    // u32 [P] first leaf of segment
-    static constexpr uint32_t oL = oF + P;                           // u32 [P] last leaf
+// Two sizes: up to 511 open roots all six box planes are tabled at once (9 levels); up to 1023 the box table holds one
+// axis (its min and its max plane, 10 levels) and is built three times -- the LDS of a CU holds no more.
+template <uint32_t P_, uint32_t LEVELS_, uint32_t NPASS_>
+struct TableCfgT {
+    static constexpr uint32_t P = P_;                 // boundaries 0 .. P-1, at most P-1 open roots
+    static constexpr uint32_t LEVELS = LEVELS_;       // windows of 1 .. 2^(LEVELS-1) entries
+    static constexpr uint32_t NPASS = NPASS_;         // builds of the box table
+    static constexpr uint32_t PLANES = 6 / NPASS_;    // box planes per build: axes [pass * PLANES/2, ...) min and max
+    static constexpr uint32_t oTab = 0;                                   // float [LEVELS-1][PLANES][P]: levels 1 .. LEVELS-1
+    static constexpr uint32_t oBox0 = oTab + (LEVELS - 1) * PLANES * P;   // float [6][P]: the open roots' boxes (level 0)
+    static constexpr uint32_t oDelta = oBox0 + 6 * P;                     // int   [LEVELS][P + 4]: minima over boundaries
+    static constexpr uint32_t oF = oDelta + LEVELS * (P + 4);             // u32 [P] first leaf of segment
+    static constexpr uint32_t oL = oF + P;                                // u32 [P] last leaf
     static constexpr uint32_t oDesc = oL + P;
     static constexpr uint32_t oCc = oDesc + P;
-    static constexpr uint32_t oIdx = oCc + P;                        // u32 [P] Karras index of the node that splits at boundary b
-    static constexpr uint32_t kDwords = oIdx + P;
+    static constexpr uint32_t oIdx = oCc + P;                             // u32 [P] Karras index of the node that splits at boundary b
+    static constexpr uint32_t oWs = oIdx + P;                             // 24 dwords of scan scratch
+    static constexpr uint32_t kDwords = oWs + 24;
     static constexpr size_t kBytes = (size_t)kDwords * 4;
 };
-static_assert(TopCfg::kBytes <= 160 * 1024, "the tables of the last level fit the LDS of a CU");
+typedef TableCfgT<512, 9, 1> TableSmall;
+typedef TableCfgT<1024, 10, 3> TableBig;
+constexpr uint32_t kTopCap = TableSmall::P - 1, kTopCapBig = TableBig::P - 1;
+static_assert(TableSmall::kBytes <= 160 * 1024 && TableBig::kBytes <= 160 * 1024, "the tables of a pass fit the LDS of a CU");
+constexpr uint32_t kNoNode = 0xFFFFFFFFu;   // nd_idx: no complete node splits at this boundary
 
-__device__ __forceinline__ void top_pass(const LevelArgs& a, uint32_t* smem, uint32_t S, const uint32_t* src_rec, uint32_t so = 0)
+// FINAL: the last level (every node complete, nothing left open).  Otherwise a node is complete iff a smaller delta
+// exists on both sides inside the block (its outer boundaries included); complete nodes whose parent is not complete
+// here, and segments in the same situation, are this block's open roots: records for the next level, in leaf order.
+template <bool FINAL, typename T>
+__device__ __forceinline__ void table_pass(const LevelArgs& a, uint32_t* smem, uint32_t S, const uint32_t* src_rec,
+                                           uint32_t* out_cnt, uint32_t* out_rec, uint32_t so = 0)
 {
-    using T = TopCfg;
     (void)so;
     RT_STAMP(1, so);
-    constexpr uint32_t P = T::P;
-    float* tb = reinterpret_cast<float*>(smem + T::oBox);
+    constexpr uint32_t P = T::P, LEVELS = T::LEVELS, NPASS = T::NPASS, PLANES = T::PLANES, HALF = T::PLANES / 2;
+    float* tab = reinterpret_cast<float*>(smem + T::oTab);
+    float* box0 = reinterpret_cast<float*>(smem + T::oBox0);
     int* td = reinterpret_cast<int*>(smem + T::oDelta);
     uint32_t* sg_f = smem + T::oF;
     uint32_t* sg_l = smem + T::oL;
@@ -481,7 +497,9 @@ __device__ __forceinline__ void top_pass(const LevelArgs& a, uint32_t* smem, uin
     uint32_t* sg_cc = smem + T::oCc;
     uint32_t* nd_idx = smem + T::oIdx;
     const uint32_t tid = threadIdx.x;
-    auto TB = [&](uint32_t k, uint32_t c, uint32_t i) -> float& { return tb[(k * 6 + c) * P + i]; };
+    // plane p of the current build (p < HALF: min of axis pass * HALF + p; else max), window 2^k at i
+    auto TAB = [&](uint32_t k, uint32_t p, uint32_t i) -> float& { return tab[((k - 1) * PLANES + p) * P + i]; };
+    auto B0 = [&](uint32_t c, uint32_t i) -> float& { return box0[c * P + i]; };   // c: min x y z, max x y z
     auto TD = [&](uint32_t k, uint32_t i) -> int& { return td[k * (P + 4) + i]; };
 
     // the records (the prefix table that locates them lives in LDS this pass is about to overwrite: registers first)
@@ -490,94 +508,128 @@ __device__ __forceinline__ void top_pass(const LevelArgs& a, uint32_t* smem, uin
         const uint32_t* pref = smem + UpperCfg::oWs + 40;
         uint32_t pb = 0;
 #pragma unroll
-        for (uint32_t step = kUpperFan / 2; step; step >>= 1) pb += (pref[pb + step] <= tid) ? step : 0u;
+        for (uint32_t step = kPrefSlots / 2; step; step >>= 1) pb += (pref[pb + step] <= tid) ? step : 0u;
         const uint4* r = reinterpret_cast<const uint4*>(src_rec + ((size_t)pb * kMaxOpen + (tid - pref[pb])) * kRecDwords);
         r0 = r[0]; r1 = r[1]; r2 = r[2];
     }
     __syncthreads();
     if (tid < S) {
         sg_f[tid] = r0.x; sg_l[tid] = r0.y; sg_desc[tid] = r0.z; sg_cc[tid] = r0.w;
-        TB(0, 0, tid) = __uint_as_float(r1.x); TB(0, 1, tid) = __uint_as_float(r1.y); TB(0, 2, tid) = __uint_as_float(r1.z);
-        TB(0, 3, tid) = __uint_as_float(r1.w); TB(0, 4, tid) = __uint_as_float(r2.x); TB(0, 5, tid) = __uint_as_float(r2.y);
+        B0(0, tid) = __uint_as_float(r1.x); B0(1, tid) = __uint_as_float(r1.y); B0(2, tid) = __uint_as_float(r1.z);
+        B0(3, tid) = __uint_as_float(r1.w); B0(4, tid) = __uint_as_float(r2.x); B0(5, tid) = __uint_as_float(r2.y);
         TD(0, tid) = (int)r2.z;                       // boundary t = the left end of segment t
         if (tid == S - 1) TD(0, S) = (int)r2.w;       // the last boundary = the right end of the last segment
     }
     __syncthreads();
-    // sparse tables: level k holds windows of 2^k entries starting at i
-#pragma unroll 1
-    for (uint32_t k = 1; k < kTopLevels; k++) {
-        const uint32_t w = 1u << k, h = w >> 1;
-        if (tid + w <= S) {
-#pragma unroll
-            for (uint32_t c = 0; c < 3; c++) {
-                TB(k, c, tid) = fminf(TB(k - 1, c, tid), TB(k - 1, c, tid + h));
-                TB(k, 3 + c, tid) = fmaxf(TB(k - 1, 3 + c, tid), TB(k - 1, 3 + c, tid + h));
-            }
-        }
-        if (tid + w <= S + 1) TD(k, tid) = min(TD(k - 1, tid), TD(k - 1, tid + h));
-        __syncthreads();
-    }
 
-    RT_STAMP(1, so + 1);   // records in, tables built
-    // ---- the node that splits at boundary b (1 <= b <= S-1): range, Karras index
+    // ---- per build of the box table: its levels (with the delta minima in the first build), then -- in the first
+    // build -- the node that splits at boundary b (1 <= b <= S-1): range and Karras index; then the two children's boxes
+    // in this build's planes
     const uint32_t b = tid;
     const bool node = b >= 1 && b < S;
+    bool complete = false;
     uint32_t sf = 0, sl = 0, idx = 0, Lj = 0, Rj = 0;
     int pl = -1, pr = -1;
-    if (node) {
-        const int v = TD(0, b);
-        uint32_t pos = b;            // every boundary in [pos, b-1] has a larger delta than v
+    float bo[6] = {0, 0, 0, 0, 0, 0}, bp[6] = {0, 0, 0, 0, 0, 0};   // boxes of the children [sf, b-1] and [b, sl]
+#pragma unroll 1
+    for (uint32_t pass = 0; pass < NPASS; pass++) {
+        const uint32_t ax0 = pass * HALF;   // first axis of this build
+#pragma unroll 1
+        for (uint32_t k = 1; k < LEVELS; k++) {
+            const uint32_t w = 1u << k, h = w >> 1;
+            if (tid + w <= S) {
 #pragma unroll
-        for (int k = (int)kTopLevels - 1; k >= 0; k--) {
-            const uint32_t w = 1u << k;
-            if (pos >= w && TD((uint32_t)k, pos - w) > v) pos -= w;
-        }
-        uint32_t q = b + 1;          // every boundary in [b+1, q-1] has a larger delta than v
-#pragma unroll
-        for (int k = (int)kTopLevels - 1; k >= 0; k--) {
-            const uint32_t w = 1u << k;
-            if (q + w <= S + 1 && TD((uint32_t)k, q) > v) q += w;
-        }
-        if (pos == 0 || q > S) {
-            atomicOr(a.status, 1u);   // cannot happen at the last level: the outermost deltas are -1
-            pos = 1; q = S;
-        }
-        Lj = pos - 1; Rj = q;
-        sf = Lj; sl = Rj - 1;
-        pl = TD(0, Lj); pr = TD(0, Rj);
-        const bool is_root = (pl & pr) < 0;
-        idx = is_root ? 0u : (pl < pr ? sg_l[sl] : sg_f[sf]);   // a left child is numbered by its last leaf, a right child by its first
-        nd_idx[b] = idx;
-    }
-    __syncthreads();
-    if (node) {
-        auto range_box = [&](uint32_t s0, uint32_t s1, float* o) {
-            const uint32_t len = s1 - s0 + 1;
-            const uint32_t k = 31u - (uint32_t)__clz(len);
-            const uint32_t t1 = s1 + 1 - (1u << k);
-#pragma unroll
-            for (uint32_t c = 0; c < 3; c++) {
-                o[c] = fminf(TB(k, c, s0), TB(k, c, t1));
-                o[3 + c] = fmaxf(TB(k, 3 + c, s0), TB(k, 3 + c, t1));
+                for (uint32_t c = 0; c < HALF; c++) {
+                    const float lo0 = k == 1 ? B0(ax0 + c, tid) : TAB(k - 1, c, tid), lo1 = k == 1 ? B0(ax0 + c, tid + h) : TAB(k - 1, c, tid + h);
+                    const float hi0 = k == 1 ? B0(3 + ax0 + c, tid) : TAB(k - 1, HALF + c, tid), hi1 = k == 1 ? B0(3 + ax0 + c, tid + h) : TAB(k - 1, HALF + c, tid + h);
+                    TAB(k, c, tid) = fminf(lo0, lo1);
+                    TAB(k, HALF + c, tid) = fmaxf(hi0, hi1);
+                }
             }
-        };
+            if (pass == 0 && tid + w <= S + 1) TD(k, tid) = min(TD(k - 1, tid), TD(k - 1, tid + h));
+            __syncthreads();
+        }
+        if (pass == 0 && node) {
+            const int v = TD(0, b);
+            uint32_t pos = b;            // every boundary in [pos, b-1] has a larger delta than v
+#pragma unroll
+            for (int k = (int)LEVELS - 1; k >= 0; k--) {
+                const uint32_t w = 1u << k;
+                if (pos >= w && TD((uint32_t)k, pos - w) > v) pos -= w;
+            }
+            uint32_t q = b + 1;          // every boundary in [b+1, q-1] has a larger delta than v
+#pragma unroll
+            for (int k = (int)LEVELS - 1; k >= 0; k--) {
+                const uint32_t w = 1u << k;
+                if (q + w <= S + 1 && TD((uint32_t)k, q) > v) q += w;
+            }
+            complete = pos > 0 && q <= S;
+            if (FINAL && !complete) {
+                atomicOr(a.status, 1u);   // cannot happen at the last level: the outermost deltas are -1
+                pos = 1; q = S; complete = true;
+            }
+            if (complete) {
+                Lj = pos - 1; Rj = q;
+                sf = Lj; sl = Rj - 1;
+                pl = TD(0, Lj); pr = TD(0, Rj);
+                const bool is_root = (pl & pr) < 0;
+                idx = is_root ? 0u : (pl < pr ? sg_l[sl] : sg_f[sf]);   // a left child is numbered by its last leaf, a right child by its first
+            }
+        }
+        if (complete) {
+            // union over [s0, s1] of this build's planes: two overlapping windows of 2^k entries (min / max: exact)
+            auto range_planes = [&](uint32_t s0, uint32_t s1, float* o) {
+                const uint32_t k = 31u - (uint32_t)__clz(s1 - s0 + 1);
+                const uint32_t t1 = s1 + 1 - (1u << k);
+#pragma unroll
+                for (uint32_t c = 0; c < HALF; c++) {
+                    const float lo0 = k == 0 ? B0(ax0 + c, s0) : TAB(k, c, s0), lo1 = k == 0 ? B0(ax0 + c, t1) : TAB(k, c, t1);
+                    const float hi0 = k == 0 ? B0(3 + ax0 + c, s0) : TAB(k, HALF + c, s0), hi1 = k == 0 ? B0(3 + ax0 + c, t1) : TAB(k, HALF + c, t1);
+                    o[ax0 + c] = fminf(lo0, lo1);
+                    o[3 + ax0 + c] = fmaxf(hi0, hi1);
+                }
+            };
+            range_planes(sf, b - 1, bo);
+            range_planes(b, sl, bp);
+        }
+        if (pass + 1 < NPASS) __syncthreads();   // the table is rebuilt
+    }
+
+    RT_STAMP(1, so + 1);   // tables built, ranges and child boxes known
+    if (tid <= S) nd_idx[tid] = complete ? idx : kNoNode;   // (boundaries 0 and S split no node of this block)
+    __syncthreads();
+    // is the node that splits at boundary pb complete here?  (the parent of whatever ends at pb with the larger delta)
+    auto parent_of = [&](int dleft, int dright, uint32_t bl, uint32_t br, uint32_t& side) -> uint32_t {
+        side = dleft < dright ? 0u : 1u;                     // my sibling is on the right: I am the left child
+        const uint32_t pb = dleft < dright ? br : bl;
+        return (pb >= 1 && pb < S) ? nd_idx[pb] : kNoNode;
+    };
+    bool node_open = false;
+    uint32_t cc_node = 0;
+    if (complete) {
         // children: segments [sf, b-1] and [b, sl]; a single segment is the open root itself, else an internal node of this
         // pass (left children are numbered by their last leaf, right children by their first)
         const bool singleL = sf == b - 1, singleR = b == sl;
-        float bo[6], bp[6];
-        range_box(sf, b - 1, bo);
-        range_box(b, sl, bp);
         const uint32_t dO = singleL ? sg_desc[sf] : (((sg_l[b - 1] * 2) & kIndexMask) | ((uint32_t)RT_CHILD_BOX << 29));
         const uint32_t dP = singleR ? sg_desc[sl] : (((sg_f[b] * 2) & kIndexMask) | ((uint32_t)RT_CHILD_BOX << 29));
         const bool boxO = (dO >> 29) == RT_CHILD_BOX, boxP = (dP >> 29) == RT_CHILD_BOX;
         const bool is_root = (pl & pr) < 0;
         uint32_t* nw = reinterpret_cast<uint32_t*>(a.nodes + (size_t)idx * 2);
-        // my own parent words: my parent splits at the end of my range that has the larger delta
-        const uint32_t side = pl < pr ? 0u : 1u;
-        const uint32_t pslot = is_root ? 0u : nd_idx[pl < pr ? Rj : Lj] * 2 + side;
-        *reinterpret_cast<uint4*>(nw + 0) = make_uint4(__float_as_uint(bo[0]), __float_as_uint(bo[1]), __float_as_uint(bo[2]), pslot | ((boxO ? 2u : 1u) << 29));
+        // my own parent words: my parent splits at the end of my range that has the larger delta.  If it is not complete
+        // here, the level that completes it writes them -- and this one must not touch them (two writers of the same
+        // bytes from different XCDs inside one launch)
+        uint32_t side;
+        const uint32_t pidx = is_root ? 0u : parent_of(pl, pr, Lj, Rj, side);
+        cc_node = (boxO ? 1u : 0u) | (boxP ? 2u : 0u);
+        node_open = !is_root && pidx == kNoNode;
+        if (!node_open) {
+            const uint32_t pslot = is_root ? 0u : pidx * 2 + side;
+            nw[3] = pslot | ((boxO ? 2u : 1u) << 29);
+            nw[11] = pslot | ((boxP ? 2u : 1u) << 29);
+        }
+        nw[0] = __float_as_uint(bo[0]); nw[1] = __float_as_uint(bo[1]); nw[2] = __float_as_uint(bo[2]);
         *reinterpret_cast<uint4*>(nw + 4) = make_uint4(__float_as_uint(bo[3]), __float_as_uint(bo[4]), __float_as_uint(bo[5]), dO);
-        *reinterpret_cast<uint4*>(nw + 8) = make_uint4(__float_as_uint(bp[0]), __float_as_uint(bp[1]), __float_as_uint(bp[2]), pslot | ((boxP ? 2u : 1u) << 29));
+        nw[8] = __float_as_uint(bp[0]); nw[9] = __float_as_uint(bp[1]); nw[10] = __float_as_uint(bp[2]);
         *reinterpret_cast<uint4*>(nw + 12) = make_uint4(__float_as_uint(bp[3]), __float_as_uint(bp[4]), __float_as_uint(bp[5]), dP);
         // a child that is an open root of the level below: its pair exists already, its parent words are mine to write
         if (singleL && boxO) {
@@ -593,8 +645,52 @@ __device__ __forceinline__ void top_pass(const LevelArgs& a, uint32_t* smem, uin
             c[11] = (idx * 2 + 1) | (((cc & 2u) ? 2u : 1u) << 29);
         }
     }
-    __syncthreads();   // LDS is reused
     RT_STAMP(1, so + 2);
+    if (!FINAL) {
+        // ---- open roots, in leaf order: an open root is identified by the segment it starts at
+        bool seg_open = false;
+        if (tid < S) {
+            uint32_t side;
+            seg_open = parent_of(TD(0, tid), TD(0, tid + 1), tid, tid + 1, side) == kNoNode;
+        }
+        __syncthreads();                       // nd_idx has been read by everybody: it becomes the flag / rank array
+        nd_idx[tid < P ? tid : 0] = 0u;        // (1024 threads, P <= 1024 entries)
+        __syncthreads();
+        if (seg_open) nd_idx[tid] = 1u;
+        if (node_open) nd_idx[sf] = 1u;        // (a segment inside a complete node is not open: no clash)
+        __syncthreads();
+        uint32_t total;
+        uint32_t* ws = smem + T::oWs;
+        const uint32_t rank = block_excl_scan_u32<1024>(tid < S ? nd_idx[tid] : 0u, ws, &total);
+        if (tid < P) nd_idx[tid] = rank;
+        __syncthreads();
+        if (seg_open) {
+            const uint32_t j = nd_idx[tid];
+            if (j < kMaxOpen) {
+                uint4* o = reinterpret_cast<uint4*>(out_rec + (size_t)j * kRecDwords);
+                store_sc1(o + 0, sg_f[tid], sg_l[tid], sg_desc[tid], sg_cc[tid]);
+                store_sc1(o + 1, __float_as_uint(B0(0, tid)), __float_as_uint(B0(1, tid)), __float_as_uint(B0(2, tid)), __float_as_uint(B0(3, tid)));
+                store_sc1(o + 2, __float_as_uint(B0(4, tid)), __float_as_uint(B0(5, tid)), (uint32_t)TD(0, tid), (uint32_t)TD(0, tid + 1));
+            }
+        }
+        if (node_open) {
+            const uint32_t j = nd_idx[sf];
+            if (j < kMaxOpen) {
+                float u[6];
+#pragma unroll
+                for (int c = 0; c < 3; c++) { u[c] = fminf(bo[c], bp[c]); u[3 + c] = fmaxf(bo[3 + c], bp[3 + c]); }
+                uint4* o = reinterpret_cast<uint4*>(out_rec + (size_t)j * kRecDwords);
+                store_sc1(o + 0, sg_f[sf], sg_l[sl], ((idx * 2) & kIndexMask) | ((uint32_t)RT_CHILD_BOX << 29), cc_node);
+                store_sc1(o + 1, __float_as_uint(u[0]), __float_as_uint(u[1]), __float_as_uint(u[2]), __float_as_uint(u[3]));
+                store_sc1(o + 2, __float_as_uint(u[4]), __float_as_uint(u[5]), (uint32_t)pl, (uint32_t)pr);
+            }
+        }
+        if (tid == 0) {
+            store_sc1(out_cnt, min(total, kMaxOpen));
+            if (total > kMaxOpen) atomicOr(a.status, 1u);  // cannot happen: <= 2 * depth(62) open roots
+        }
+    }
+    __syncthreads();   // LDS is reused
     RT_STAMP(1, so + 3);
     RT_STAMP(1, so + 4);
 }
@@ -654,8 +750,16 @@ __global__ __launch_bounds__(1024) void lbvh_upper_kernel(LevelArgs a)
         const uint32_t S = load_prefix(smem, src_cnt, nb);
         RT_STAMP(1, 1 + (lvl - 1) * 7);
         // (the test variant of the library keeps the climb at the last level too: it exists to exercise the sub-pass path)
-        if (RT_LBVH_FAST_CAP == kCap && lvl + 1 == a.num_levels && S >= 2 && S <= kTopCap) {
-            top_pass(a, smem, S, src_rec, 2 + (lvl - 1) * 7);
+        const bool last = lvl + 1 == a.num_levels;
+        if (RT_LBVH_FAST_CAP == kCap && S >= (last ? 2u : 1u) && S <= kTopCapBig) {
+            const uint32_t so = 2 + (lvl - 1) * 7;
+            if (S <= kTopCap) {
+                if (last) table_pass<true, TableSmall>(a, smem, S, src_rec, out_cnt, out_rec, so);
+                else table_pass<false, TableSmall>(a, smem, S, src_rec, out_cnt, out_rec, so);
+            } else {
+                if (last) table_pass<true, TableBig>(a, smem, S, src_rec, out_cnt, out_rec, so);
+                else table_pass<false, TableBig>(a, smem, S, src_rec, out_cnt, out_rec, so);
+            }
         } else if (S <= RT_LBVH_FAST_CAP) {
             level_pass<false>(a, smem, n, 0, S, src_rec, out_cnt, out_rec, 2 + (lvl - 1) * 7);
         } else {
@@ -738,7 +842,8 @@ LevelPlan lbvh_level_plan(uint32_t n)
     return p;
 }
 
-constexpr size_t kUpperLds = UpperCfg::kBytes > TopCfg::kBytes ? UpperCfg::kBytes : TopCfg::kBytes;
+constexpr size_t kUpperLds = TableBig::kBytes > UpperCfg::kBytes ? TableBig::kBytes : UpperCfg::kBytes;
+static_assert(TableSmall::kBytes <= kUpperLds, "one LDS size for every pass of the upper kernel");
 
 hipError_t launch_lbvh_levels(const rt_triangle* tris, const uint32_t* codes, const uint32_t* sorted_indices,
                               uint32_t n, rt_triangle_pair* leaves, rt_node* nodes, void* level_scratch,

@@ -52,12 +52,12 @@ t = up[used]
 t = t[:, :21]
 t0 = t[:, 0].min()
 print(f"upper kernel: {used.sum()} workgroups; first start -> last stamp {us(t.max() - t0):.2f} us")
-lab = ["entry", "L1 prefix", "L1 pass entry", "L1 init", "L1 climb", "L1 (no sweep)", "L1 records out",
-       "L2 ticket", "L2 prefix", "L2 pass entry", "L2 init", "L2 climb", "L2 -", "L2 records out",
-       "L3 ticket", "L3 prefix", "L3 pass entry", "L3 init", "L3 climb", "L3 -", "L3 records out"]
+lab = ["entry", "L1 prefix", "L1 pass entry", "L1 init | tables + ranges", "L1 climb | nodes", "L1 -", "L1 records out",
+       "L2 ticket", "L2 prefix", "L2 pass entry", "L2 init | tables + ranges", "L2 climb | nodes", "L2 -", "L2 records out",
+       "L3 ticket", "L3 prefix", "L3 pass entry", "L3 init | tables + ranges", "L3 climb | nodes", "L3 -", "L3 records out"]
 for k, nm in enumerate(lab):
     col = t[:, k]
     ok = col > 0
     if ok.any():
         v = us(col[ok] - t0)
-        print(f"  {nm:16s} reached by {ok.sum():4d}: at avg {v.mean():7.2f}  min {v.min():7.2f}  max {v.max():7.2f} us after the first workgroup's start")
+        print(f"  {nm:26s} reached by {ok.sum():4d}: at avg {v.mean():7.2f}  min {v.min():7.2f}  max {v.max():7.2f} us after the first workgroup's start")
