@@ -32,6 +32,15 @@
 //     there is no spin and no dependence on dispatch order, a workgroup either continues upward or
 //     exits.  (Chaining the leaf level into the same launch was measured slower: the leaf pass then
 //     shares its register budget with the upper passes.)
+//   * an upper pass over at most 1023 open roots does not climb at all (table_pass): the node that splits
+//     at a boundary reaches on either side to the nearest boundary with a smaller delta, so one thread per
+//     boundary finds its node's range by binary descents over a sparse table of delta minima, takes its
+//     two children's boxes as range unions from sparse tables of boxes, and derives its Karras index, its
+//     parent and its side from the range -- no node waits for another.  A climb lasts as long as the
+//     deepest path of its tree (16 - 22 dependent merges of about 0.85 us each in these passes); the table
+//     pass takes 7 - 12 us whatever the tree looks like.  The climb (level_pass) is what the leaf level
+//     runs -- there the data movement, not the climb, is most of the time -- and the fallback for larger
+//     upper passes.
 //
 // Node words: w28 = child:29|type:3 and the box of a slot are written by the workgroup that completes
 // the OWNING node; w12 = parent:29|count:3 of a pair is written by whoever completes the pair's parent
