@@ -543,19 +543,34 @@ __device__ __forceinline__ void table_pass(const LevelArgs& a, uint32_t* smem, u
 #pragma unroll 1
     for (uint32_t pass = 0; pass < NPASS; pass++) {
         const uint32_t ax0 = pass * HALF;   // first axis of this build
+        // two levels per barrier: level k from two windows of level k-1, level k+1 from four
 #pragma unroll 1
-        for (uint32_t k = 1; k < LEVELS; k++) {
-            const uint32_t w = 1u << k, h = w >> 1;
-            if (tid + w <= S) {
+        for (uint32_t k = 1; k < LEVELS; k += 2) {
+            const uint32_t h = 1u << (k - 1);
+            const bool two = k + 1 < LEVELS;
+            const bool in1 = tid + 2 * h <= S, in2 = two && tid + 4 * h <= S;
+            if (in1) {
 #pragma unroll
                 for (uint32_t c = 0; c < HALF; c++) {
-                    const float lo0 = k == 1 ? B0(ax0 + c, tid) : TAB(k - 1, c, tid), lo1 = k == 1 ? B0(ax0 + c, tid + h) : TAB(k - 1, c, tid + h);
-                    const float hi0 = k == 1 ? B0(3 + ax0 + c, tid) : TAB(k - 1, HALF + c, tid), hi1 = k == 1 ? B0(3 + ax0 + c, tid + h) : TAB(k - 1, HALF + c, tid + h);
-                    TAB(k, c, tid) = fminf(lo0, lo1);
-                    TAB(k, HALF + c, tid) = fmaxf(hi0, hi1);
+                    auto lo = [&](uint32_t i) { return k == 1 ? B0(ax0 + c, i) : TAB(k - 1, c, i); };
+                    auto hi = [&](uint32_t i) { return k == 1 ? B0(3 + ax0 + c, i) : TAB(k - 1, HALF + c, i); };
+                    const float l01 = fminf(lo(tid), lo(tid + h)), h01 = fmaxf(hi(tid), hi(tid + h));
+                    TAB(k, c, tid) = l01;
+                    TAB(k, HALF + c, tid) = h01;
+                    if (in2) {
+                        TAB(k + 1, c, tid) = fminf(l01, fminf(lo(tid + 2 * h), lo(tid + 3 * h)));
+                        TAB(k + 1, HALF + c, tid) = fmaxf(h01, fmaxf(hi(tid + 2 * h), hi(tid + 3 * h)));
+                    }
                 }
             }
-            if (pass == 0 && tid + w <= S + 1) TD(k, tid) = min(TD(k - 1, tid), TD(k - 1, tid + h));
+            if (pass == 0) {
+                const bool d1 = tid + 2 * h <= S + 1, d2 = two && tid + 4 * h <= S + 1;
+                if (d1) {
+                    const int m01 = min(TD(k - 1, tid), TD(k - 1, tid + h));
+                    TD(k, tid) = m01;
+                    if (d2) TD(k + 1, tid) = min(m01, min(TD(k - 1, tid + 2 * h), TD(k - 1, tid + 3 * h)));
+                }
+            }
             __syncthreads();
         }
         if (pass == 0 && node) {
