@@ -543,8 +543,9 @@ __device__ __forceinline__ void table_pass(const LevelArgs& a, uint32_t* smem, u
 #pragma unroll 1
     for (uint32_t pass = 0; pass < NPASS; pass++) {
         const uint32_t ax0 = pass * HALF;   // first axis of this build
-        // two levels per barrier: level k from two windows of level k-1, level k+1 from four
-#pragma unroll 1
+        // two levels per barrier: level k from two windows of level k-1, level k+1 from four (unrolled: the steps are
+        // bound by instruction issue -- every thread of the workgroup takes part -- and k decides addresses)
+#pragma unroll
         for (uint32_t k = 1; k < LEVELS; k += 2) {
             const uint32_t h = 1u << (k - 1);
             const bool two = k + 1 < LEVELS;
