@@ -449,18 +449,18 @@ __device__ __forceinline__ uint32_t load_prefix(uint32_t* smem, const uint32_t* 
     return pref[kPrefSlots];
 }
 
-// ---- the LAST level by range searches instead of a climb.
+// ---- an upper pass by range searches instead of a climb (table_pass).
 //
-// The climb of a pass is a chain of dependent merges as long as the deepest path of its tree (22 for the 310 open roots
-// the 1M build's last level folds, at about 0.85 us each: profiles/r02_lbvh_phases_1m.txt).  The last level has no such
-// need: every node it makes is complete, and a node of a radix tree is determined by its split alone -- the node that
-// splits at boundary b reaches, on either side, to the nearest boundary with a SMALLER delta (inside a node every other
-// boundary has a larger delta than its split, and the two ends have smaller ones).  So one thread per boundary finds its
-// node's range with two binary descents over a sparse table of delta minima, the boxes of its two children are two
-// range unions from a sparse table of boxes (min / max are exact and idempotent: two overlapping power-of-two windows),
-// and the Karras indices follow from the ranges as in the climb.  No dependence between nodes: 9 barrier-separated table
-// levels + two short phases instead of 22 dependent merges.  Same Node words as the climb (tests: every build whose
-// last level holds 2 .. 511 open roots takes this path).
+// The climb of a pass is a chain of dependent merges as long as the deepest path of its tree (16 - 22 for the 300 - 650
+// open roots the upper passes of the 1M build fold, at about 0.85 us each).  A node of a radix tree is determined by its
+// split alone: the node that splits at boundary b reaches, on either side, to the nearest boundary with a SMALLER delta
+// (inside a node every other boundary has a larger delta than its split, and the two ends have smaller ones).  So one
+// thread per boundary finds its node's range with two binary descents over a sparse table of delta minima; the boxes of
+// its two children are two range unions from sparse tables of boxes (min / max are exact and idempotent: two
+// overlapping power-of-two windows); the Karras index, the parent (the node that splits at the end with the larger
+// delta) and the side follow from the range.  No dependence between nodes: a few barrier-separated table steps and two
+// short phases.  Same Node words and the same open-root records as the climb (tests: every upper pass of 1 .. 1023 open
+// roots takes this path; the climb keeps the larger ones and the test variant of the library).
 // Two sizes: up to 511 open roots all six box planes are tabled at once (9 levels); up to 1023 the box table holds one
 // axis (its min and its max plane, 10 levels) and is built three times -- the LDS of a CU holds no more.
 template <uint32_t P_, uint32_t LEVELS_, uint32_t NPASS_>
