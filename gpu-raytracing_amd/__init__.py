@@ -96,7 +96,7 @@ class _SahScratchLayout(ctypes.Structure):
 EXPORTS = ["rt_bu_memory_requirements", "rt_nodes_bytes", "rt_run_bottom_up_build", "rt_bu_scratch_layout_get",
            "rt_sah_memory_requirements", "rt_run_sah_build", "rt_sah_scratch_layout_get",
            "rt_calculate_scene_aabb", "rt_generate_morton_codes", "rt_radix_sort_scratch_bytes",
-           "rt_radix_sort_u32_pairs", "rt_trace", "rt_trace_strips", "rt_error_string", "rt_version_string"]
+           "rt_radix_sort_u32_pairs", "rt_radix_sort_u32_pairs_bits", "rt_radix_sort_input_in_tmp", "rt_trace", "rt_trace_strips", "rt_error_string", "rt_version_string"]
 
 _lib = None
 
@@ -133,6 +133,10 @@ def lib() -> ctypes.CDLL:
     L.rt_radix_sort_scratch_bytes.argtypes = [u32]
     L.rt_radix_sort_u32_pairs.restype = i32
     L.rt_radix_sort_u32_pairs.argtypes = [vp, vp, vp, vp, u32, vp, vp]
+    L.rt_radix_sort_u32_pairs_bits.restype = i32
+    L.rt_radix_sort_u32_pairs_bits.argtypes = [vp, vp, vp, vp, u32, u32, i32, vp, vp]
+    L.rt_radix_sort_input_in_tmp.restype = i32
+    L.rt_radix_sort_input_in_tmp.argtypes = [u32, u32]
     L.rt_trace.restype = i32
     L.rt_trace.argtypes = [ctypes.POINTER(_Accel), ctypes.POINTER(_Scene), vp, i32, vp, u32, u32, u32, u32, u32, vp]
     L.rt_trace_strips.restype = i32
@@ -279,6 +283,16 @@ def RadixSort(keys, values, temp1, temp2, count: int, sort_scratch=None, stream=
         sort_scratch = device_bytes(int(lib().rt_radix_sort_scratch_bytes(count)), keys.device)
     _check(lib().rt_radix_sort_u32_pairs(_ptr(keys), _ptr(values), _ptr(temp1), _ptr(temp2), count,
                                          _ptr(sort_scratch), _stream_ptr(stream)), "rt_radix_sort_u32_pairs")
+
+
+def RadixSortBits(keys, values, temp1, temp2, count: int, key_bits: int, input_in_tmp: bool = False, sort_scratch=None,
+                  stream=None) -> None:
+    """rt_radix_sort_u32_pairs_bits: the sort for keys of `key_bits` significant bits (the builder's Morton codes: 30)."""
+    if sort_scratch is None:
+        sort_scratch = device_bytes(int(lib().rt_radix_sort_scratch_bytes(count)), keys.device)
+    _check(lib().rt_radix_sort_u32_pairs_bits(_ptr(keys), _ptr(values), _ptr(temp1), _ptr(temp2), count, key_bits,
+                                              int(input_in_tmp), _ptr(sort_scratch), _stream_ptr(stream)),
+           "rt_radix_sort_u32_pairs_bits")
 
 
 def RadixSortScratchBytes(count: int) -> int:

@@ -185,14 +185,15 @@ __global__ __launch_bounds__(256) void morton_kernel(uint32_t* __restrict__ code
     values[gid] = gid;
 }
 
-// Morton codes + the tile histograms of the sort's first pass in one launch: a workgroup owns one sort tile (4096
-// triangles, 16 per thread: each lane reads its 36-byte triangle directly -- neighbouring lanes use the rest of every
-// line) and counts the low BITS bits of its codes in LDS exactly as sort_upsweep_kernel would.
+// Morton codes + the group histograms of the sort's first pass in one launch: a workgroup owns one group of sort tiles
+// (4096 triangles each: every lane reads its 36-byte triangle directly -- neighbouring lanes use the rest of every
+// line) and counts the low BITS bits of its codes in LDS exactly as sort_upsweep_kernel would.  values == nullptr: the
+// identity values[i] = i (BottomUpBuilder.cu:113) is not written; the sort's first pass regenerates it.
 template <uint32_t BITS, uint32_t NT>
 __global__ __launch_bounds__(NT) void morton_hist_kernel(uint32_t* __restrict__ codes, uint32_t* __restrict__ values,
                                                           const float* __restrict__ f, const int* __restrict__ aabb,
                                                           uint32_t n, uint32_t nparts, int* __restrict__ aabb_out,
-                                                          uint32_t* __restrict__ hist, uint32_t num_tiles)
+                                                          uint32_t* __restrict__ hist, uint32_t num_tiles, uint32_t tpw)
 {
     constexpr uint32_t RADIX = 1u << BITS;
     __shared__ uint32_t h[RADIX];
@@ -201,41 +202,45 @@ __global__ __launch_bounds__(NT) void morton_hist_kernel(uint32_t* __restrict__ 
     for (uint32_t d = threadIdx.x; d < RADIX; d += NT) h[d] = 0;
     fold_scene_box(aabb, nparts, sbox, bmin, bmax);   // (its barriers also order the zeroing of h)
     if (aabb_out && blockIdx.x == 0 && threadIdx.x < 6) aabb_out[threadIdx.x] = sbox[threadIdx.x];
-    const uint32_t tile = blockIdx.x, base = tile * kSortTile;
+    const uint32_t group = blockIdx.x, num_groups = gridDim.x;
+    const uint32_t t0 = group * tpw, t1 = min(t0 + tpw, num_tiles);
     const int lane = threadIdx.x & 63;
     const float minx = bmin[0], miny = bmin[1], minz = bmin[2], maxx = bmax[0], maxy = bmax[1], maxz = bmax[2];
+    for (uint32_t tile = t0; tile < t1; tile++) {
+        const uint32_t base = tile * kSortTile;
 #pragma unroll 4
-    for (uint32_t i = 0; i < kSortTile / NT; i++) {
-        const uint32_t gid = base + i * NT + threadIdx.x;
-        const bool valid = gid < n;
-        uint32_t code = 0;
-        if (valid) {
-            float t[9];
-            load_tri9(f + (size_t)gid * 9, t);
-            float cx = ((t[0] + t[3]) + t[6]) / 3.0f;
-            float cy = ((t[1] + t[4]) + t[7]) / 3.0f;
-            float cz = ((t[2] + t[5]) + t[8]) / 3.0f;
-            cx = (cx - minx) / (maxx - minx);
-            cy = (cy - miny) / (maxy - miny);
-            cz = (cz - minz) / (maxz - minz);
-            cx = fmaxf(0.0f, fminf(cx, 1.0f));
-            cy = fmaxf(0.0f, fminf(cy, 1.0f));
-            cz = fmaxf(0.0f, fminf(cz, 1.0f));
-            code = morton3d(cx, cy, cz);
-            codes[gid] = code;
-            values[gid] = gid;
-        }
-        const uint32_t d = code & (RADIX - 1);
-        const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
-        if (__popcll(__ballot(valid && d == d0)) >= 8) {
-            const uint64_t m = match_digit<BITS>(d, valid);
-            if (valid && lane == __ffsll((unsigned long long)m) - 1) atomicAdd(&h[d], (uint32_t)__popcll(m));
-        } else if (valid) {
-            atomicAdd(&h[d], 1u);
+        for (uint32_t i = 0; i < kSortTile / NT; i++) {
+            const uint32_t gid = base + i * NT + threadIdx.x;
+            const bool valid = gid < n;
+            uint32_t code = 0;
+            if (valid) {
+                float t[9];
+                load_tri9(f + (size_t)gid * 9, t);
+                float cx = ((t[0] + t[3]) + t[6]) / 3.0f;
+                float cy = ((t[1] + t[4]) + t[7]) / 3.0f;
+                float cz = ((t[2] + t[5]) + t[8]) / 3.0f;
+                cx = (cx - minx) / (maxx - minx);
+                cy = (cy - miny) / (maxy - miny);
+                cz = (cz - minz) / (maxz - minz);
+                cx = fmaxf(0.0f, fminf(cx, 1.0f));
+                cy = fmaxf(0.0f, fminf(cy, 1.0f));
+                cz = fmaxf(0.0f, fminf(cz, 1.0f));
+                code = morton3d(cx, cy, cz);
+                codes[gid] = code;
+                if (values) values[gid] = gid;
+            }
+            const uint32_t d = code & (RADIX - 1);
+            const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+            if (__popcll(__ballot(valid && d == d0)) >= 8) {
+                const uint64_t m = match_digit<BITS>(d, valid);
+                if (valid && lane == __ffsll((unsigned long long)m) - 1) atomicAdd(&h[d], (uint32_t)__popcll(m));
+            } else if (valid) {
+                atomicAdd(&h[d], 1u);
+            }
         }
     }
     __syncthreads();
-    for (uint32_t d = threadIdx.x; d < RADIX; d += NT) hist[(size_t)d * num_tiles + tile] = h[d];
+    for (uint32_t d = threadIdx.x; d < RADIX; d += NT) hist[(size_t)d * num_groups + group] = h[d];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -407,12 +412,13 @@ hipError_t launch_morton_hist(uint32_t* codes, uint32_t* values, const rt_triang
 {
     if (n == 0) return hipSuccess;
     const uint32_t tiles = sort_num_tiles(n);
+    const uint32_t tpw = sort_tiles_per_group(tiles), groups = (tiles + tpw - 1) / tpw;   // the sort's own grouping
     const float* f = reinterpret_cast<const float*>(tris);
     // few tiles (the 3 x 10-bit regime): 1024 threads per tile (4 triangles each) -- a pass over 245 tiles is one workgroup's chain
     if (bits == 10)
-        morton_hist_kernel<10, 1024><<<tiles, 1024, 0, st>>>(codes, values, f, aabb, n, nparts ? nparts : 1u, aabb_out, hist, tiles);
+        morton_hist_kernel<10, 1024><<<groups, 1024, 0, st>>>(codes, values, f, aabb, n, nparts ? nparts : 1u, aabb_out, hist, tiles, tpw);
     else
-        morton_hist_kernel<8, 256><<<tiles, 256, 0, st>>>(codes, values, f, aabb, n, nparts ? nparts : 1u, aabb_out, hist, tiles);
+        morton_hist_kernel<8, 256><<<groups, 256, 0, st>>>(codes, values, f, aabb, n, nparts ? nparts : 1u, aabb_out, hist, tiles, tpw);
     return hipGetLastError();
 }
 

@@ -65,6 +65,23 @@ __device__ unsigned long long g_stamp[2][kStampBlocks * kStampSlots];
 #define RT_STAMP(arr, k) do { } while (0)
 #endif
 
+// Error flags of the build's status word (rt_bu_scratch_layout.status[0]).  Every global address this file forms from a
+// word it has read from memory -- the sorted triangle index, a hand-off record's leaf range and node descriptor -- is
+// range-checked first: a corrupt word (an upstream stage that failed, stale scratch) raises a flag and is replaced by a
+// harmless value instead of becoming a wild address (a GPU memory-access fault takes the process down).
+constexpr uint32_t kErrOpenOverflow = 1u;   // more than kMaxOpen open roots in one block (impossible: depth <= 62)
+constexpr uint32_t kErrSortedIndex = 2u;    // sorted_idx[i] does not name a triangle of the input
+constexpr uint32_t kErrRecord = 4u;         // a hand-off record of the level below is not a sub-tree of this build
+
+// a hand-off record (f, l, desc, cc): leaves [f, l] of n, desc = a leaf (Tri, index < n) or a node pair (Box, even slot
+// index <= 2(n-2))
+__device__ __forceinline__ bool record_ok(uint32_t f, uint32_t l, uint32_t desc, uint32_t n)
+{
+    const uint32_t ix = desc & kIndexMask, ty = desc >> 29;
+    const bool d_ok = ty == RT_CHILD_TRI ? ix < n : (ty == RT_CHILD_BOX && (ix & 1u) == 0u && ix + 4 <= 2 * n);
+    return f <= l && l < n && d_ok;
+}
+
 constexpr uint32_t kLockEmpty = 0xFFFFFFFFu;
 constexpr uint32_t kLockDone = 0xFFFFFFFEu;
 constexpr uint32_t kCap = kUpperCap;  // segments an upper pass handles in LDS (the leaf pass: kLeafCap leaves)
@@ -198,6 +215,22 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
     uint32_t* sink = LEAF ? smem + C::oSink : a.sink;
     if (LEAF) {
         for (uint32_t j = tid; j < C::CAP; j += NT) stage[j * 16 + 7] = 0u;
+    } else {
+        // node addresses of this pass are formed from the records: check them all first (this climb is the fallback of the
+        // upper levels; the extra sweep over the records costs nothing that matters)
+        bool bad = false;
+        for (uint32_t s0 = tid; s0 < S; s0 += NT) {
+            const uint32_t* r = rec_ptr(s0);
+            bad |= !record_ok(r[0], r[1], r[2], n);
+        }
+        if (__syncthreads_or(bad)) {
+            if (tid == 0) {
+                atomicOr(a.status, kErrRecord);
+                store_sc1(out_cnt, 0u);
+            }
+            __syncthreads();
+            return;
+        }
     }
     for (uint32_t b = tid; b <= S; b += NT) {
         lock[b] = kLockEmpty;
@@ -225,8 +258,13 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
             // GenerateTriangles (BottomUpBuilder.cu:287-312) fused: gather the triangle, emit the
             // 64-byte leaf in sorted order (ids defined), keep its box in registers.
             const uint32_t i = B0 + s0;
-            const uint32_t sv = a.sorted_idx[i];
-            const uint32_t src = sv & 0x7FFFFFFFu;
+            uint32_t sv = a.sorted_idx[i];
+            uint32_t src = sv & 0x7FFFFFFFu;
+            // the gather address comes from memory: never past the triangle array (a quad leaf also reads triangle src + 1)
+            if (src + (sv >> 31) >= a.n) {
+                atomicOr(a.status, kErrSortedIndex);
+                sv = src = 0u;
+            }
             float v[9];
             load_tri9(a.tris + (size_t)src * 9, v);   // 36 bytes at a 4-byte-aligned address: 2 x 16-byte loads + 1 dword
             uint4* out = reinterpret_cast<uint4*>(a.leaves + i);
@@ -427,7 +465,7 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
     }
     if (tid == 0) {
         store_sc1(out_cnt, min(total, kMaxOpen));
-        if (total > kMaxOpen) atomicOr(a.status, 1u);  // cannot happen: <= 2 * depth(62) open roots
+        if (total > kMaxOpen) atomicOr(a.status, kErrOpenOverflow);  // cannot happen: <= 2 * depth(62) open roots
     }
     __syncthreads();   // LDS is reused by the next pass of this workgroup
     RT_STAMP(LEAF ? 0 : 1, so + 4);
@@ -491,7 +529,7 @@ constexpr uint32_t kNoNode = 0xFFFFFFFFu;   // nd_idx: no complete node splits a
 // exists on both sides inside the block (its outer boundaries included); complete nodes whose parent is not complete
 // here, and segments in the same situation, are this block's open roots: records for the next level, in leaf order.
 template <bool FINAL, typename T>
-__device__ __forceinline__ void table_pass(const LevelArgs& a, uint32_t* smem, uint32_t S, const uint32_t* src_rec,
+__device__ __forceinline__ void table_pass(const LevelArgs& a, uint32_t* smem, uint32_t n, uint32_t S, const uint32_t* src_rec,
                                            uint32_t* out_cnt, uint32_t* out_rec, uint32_t so = 0)
 {
     (void)so;
@@ -521,7 +559,15 @@ __device__ __forceinline__ void table_pass(const LevelArgs& a, uint32_t* smem, u
         const uint4* r = reinterpret_cast<const uint4*>(src_rec + ((size_t)pb * kMaxOpen + (tid - pref[pb])) * kRecDwords);
         r0 = r[0]; r1 = r[1]; r2 = r[2];
     }
-    __syncthreads();
+    // node addresses of this pass are formed from r0: refuse records that are not sub-trees of this build
+    if (__syncthreads_or(tid < S && !record_ok(r0.x, r0.y, r0.z, n))) {
+        if (tid == 0) {
+            atomicOr(a.status, kErrRecord);
+            if (!FINAL) store_sc1(out_cnt, 0u);
+        }
+        __syncthreads();
+        return;
+    }
     if (tid < S) {
         sg_f[tid] = r0.x; sg_l[tid] = r0.y; sg_desc[tid] = r0.z; sg_cc[tid] = r0.w;
         B0(0, tid) = __uint_as_float(r1.x); B0(1, tid) = __uint_as_float(r1.y); B0(2, tid) = __uint_as_float(r1.z);
@@ -590,7 +636,7 @@ __device__ __forceinline__ void table_pass(const LevelArgs& a, uint32_t* smem, u
             }
             complete = pos > 0 && q <= S;
             if (FINAL && !complete) {
-                atomicOr(a.status, 1u);   // cannot happen at the last level: the outermost deltas are -1
+                atomicOr(a.status, kErrOpenOverflow);   // cannot happen at the last level: the outermost deltas are -1
                 pos = 1; q = S; complete = true;
             }
             if (complete) {
@@ -712,7 +758,7 @@ __device__ __forceinline__ void table_pass(const LevelArgs& a, uint32_t* smem, u
         }
         if (tid == 0) {
             store_sc1(out_cnt, min(total, kMaxOpen));
-            if (total > kMaxOpen) atomicOr(a.status, 1u);  // cannot happen: <= 2 * depth(62) open roots
+            if (total > kMaxOpen) atomicOr(a.status, kErrOpenOverflow);  // cannot happen: <= 2 * depth(62) open roots
         }
     }
     __syncthreads();   // LDS is reused
@@ -779,11 +825,11 @@ __global__ __launch_bounds__(1024) void lbvh_upper_kernel(LevelArgs a)
         if (RT_LBVH_FAST_CAP == kCap && S >= (last ? 2u : 1u) && S <= kTopCapBig) {
             const uint32_t so = 2 + (lvl - 1) * 7;
             if (S <= kTopCap) {
-                if (last) table_pass<true, TableSmall>(a, smem, S, src_rec, out_cnt, out_rec, so);
-                else table_pass<false, TableSmall>(a, smem, S, src_rec, out_cnt, out_rec, so);
+                if (last) table_pass<true, TableSmall>(a, smem, n, S, src_rec, out_cnt, out_rec, so);
+                else table_pass<false, TableSmall>(a, smem, n, S, src_rec, out_cnt, out_rec, so);
             } else {
-                if (last) table_pass<true, TableBig>(a, smem, S, src_rec, out_cnt, out_rec, so);
-                else table_pass<false, TableBig>(a, smem, S, src_rec, out_cnt, out_rec, so);
+                if (last) table_pass<true, TableBig>(a, smem, n, S, src_rec, out_cnt, out_rec, so);
+                else table_pass<false, TableBig>(a, smem, n, S, src_rec, out_cnt, out_rec, so);
             }
         } else if (S <= RT_LBVH_FAST_CAP) {
             level_pass<false>(a, smem, n, 0, S, src_rec, out_cnt, out_rec, 2 + (lvl - 1) * 7);

@@ -99,6 +99,30 @@ int rt_radix_sort_u32_pairs(uint32_t* keys, uint32_t* values, uint32_t* tmp_keys
                                     static_cast<hipStream_t>(stream)));
 }
 
+int rt_radix_sort_u32_pairs_bits(uint32_t* keys, uint32_t* values, uint32_t* tmp_keys, uint32_t* tmp_values,
+                                 uint32_t count, uint32_t key_bits, int input_in_tmp, void* sort_scratch, void* stream)
+{
+    if (count && (!keys || !values || !tmp_keys || !tmp_values || !sort_scratch)) return RT_ERR_INVALID_ARGUMENT;
+    if (key_bits == 0 || key_bits > 32) return RT_ERR_INVALID_ARGUMENT;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // an odd number of passes (3 x 10 bits) reads its input from the temporaries, an even one (4 x 8) from keys / values:
+    // the result is in keys / values either way.  The input is moved only when it sits on the other side.
+    const bool wants_tmp = key_bits <= 30 && sort_three_passes(sort_num_tiles(count));
+    if (count && wants_tmp != (input_in_tmp != 0)) {
+        uint32_t *sk = input_in_tmp ? tmp_keys : keys, *sv = input_in_tmp ? tmp_values : values;
+        uint32_t *dk = input_in_tmp ? keys : tmp_keys, *dv = input_in_tmp ? values : tmp_values;
+        hipError_t e = hipMemcpyAsync(dk, sk, (size_t)count * 4, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(dv, sv, (size_t)count * 4, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return hip_rc(e);
+    }
+    return hip_rc(launch_radix_sort(keys, values, tmp_keys, tmp_values, count, sort_scratch, st, nullptr, key_bits));
+}
+
+int rt_radix_sort_input_in_tmp(uint32_t count, uint32_t key_bits)
+{
+    return key_bits <= 30 && sort_three_passes(sort_num_tiles(count)) ? 1 : 0;
+}
+
 int rt_run_bottom_up_build(const rt_build_input* input, const rt_arguments* args, int hybrid, void* stream)
 {
     if (!input || !input->nodes_out || !input->scratch) return RT_ERR_INVALID_ARGUMENT;
@@ -142,7 +166,7 @@ int rt_run_bottom_up_build(const rt_build_input* input, const rt_arguments* args
     // The sort of the 30-bit Morton keys: 3 passes x 10 bits while the tables stay small (kSort3PassMaxTiles), else 4 x 8.
     // An odd number of passes ends in the other buffer pair, so the Morton kernels then write into the temporaries.
     // Without --pairs the Morton kernel also produces the first pass's tile histograms (one launch fewer).
-    const bool three = sort_num_tiles(n) <= kSort3PassMaxTiles;
+    const bool three = sort_three_passes(sort_num_tiles(n));
     uint32_t* code_dst = three ? tmpk : morton;
     uint32_t* value_dst = three ? tmpv : sorted;
     if (e == hipSuccess) {
@@ -150,10 +174,12 @@ int rt_run_bottom_up_build(const rt_build_input* input, const rt_arguments* args
             e = launch_morton_pairs(code_dst, value_dst, input->triangles_in, aabb_parts, n, reinterpret_cast<uint8_t*>(s + L.pair_flags),
                                     reinterpret_cast<uint32_t*>(s + L.pair_sums), num_leaves, st, nparts, p_aabb);
         else
-            e = launch_morton_hist(code_dst, value_dst, input->triangles_in, aabb_parts, n, st, nparts, p_aabb,
+            // (the values of this path are the identity, BottomUpBuilder.cu:113: not written, the sort's first pass regenerates them)
+            e = launch_morton_hist(code_dst, nullptr, input->triangles_in, aabb_parts, n, st, nparts, p_aabb,
                                    sort_hist_table(s + L.sort, n), three ? 10 : 8);
     }
-    if (e == hipSuccess) e = launch_radix_sort(morton, sorted, tmpk, tmpv, n, s + L.sort, st, n_dev, three ? 30 : 32, !pairs);
+    if (e == hipSuccess)
+        e = launch_radix_sort(morton, sorted, tmpk, tmpv, n, s + L.sort, st, n_dev, three ? 30 : 32, !pairs, !pairs);
     if (e == hipSuccess)
         e = launch_lbvh_levels(input->triangles_in, morton, sorted, n, input->triangles_out, input->nodes_out,
                                s + L.levels, status, st, n_dev);

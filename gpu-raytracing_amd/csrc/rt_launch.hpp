@@ -115,6 +115,7 @@ hipError_t launch_morton(uint32_t* codes, uint32_t* values, const rt_triangle* t
                          hipStream_t st, uint32_t nparts = 1, int* aabb_out = nullptr);
 // the same codes / values plus the first sort pass's tile histograms (digit = low `bits` bits, bits = 8 or 10) in one
 // launch: one workgroup per sort tile
+// values == nullptr: they are not written (the sort's first pass then takes them as the identity)
 hipError_t launch_morton_hist(uint32_t* codes, uint32_t* values, const rt_triangle* tris, const int* aabb, uint32_t n,
                               hipStream_t st, uint32_t nparts, int* aabb_out, uint32_t* hist, uint32_t bits);
 hipError_t launch_morton_pairs(uint32_t* codes, uint32_t* values, const rt_triangle* tris, const int* aabb, uint32_t n,
@@ -123,9 +124,13 @@ hipError_t launch_morton_pairs(uint32_t* codes, uint32_t* values, const rt_trian
 // n_dev (may be null): device word holding the real element count (<= n); n then only sizes the grids.
 // key_bits <= 30 (Morton keys): 3 passes of 10 bits, and the INPUT is taken from (tmp_keys, tmp_vals); the sorted result
 // is in (keys, vals) either way.
+// have_hist0: the first pass's group histograms are already in the sort scratch (launch_morton_hist wrote them).
+// ident0: the input values are the identity (values[i] = i) and are not read.
 hipError_t launch_radix_sort(uint32_t* keys, uint32_t* vals, uint32_t* tmp_keys, uint32_t* tmp_vals, uint32_t n,
                              void* sort_scratch, hipStream_t st, const uint32_t* n_dev = nullptr, uint32_t key_bits = 32,
-                             bool have_hist0 = false);
+                             bool have_hist0 = false, bool ident0 = false);
+bool sort_three_passes(uint32_t tiles);          // keys of <= 30 bits: 3 x 10-bit passes (else 4 x 8)
+uint32_t sort_tiles_per_group(uint32_t tiles);   // consecutive tiles one workgroup works through
 // the builder's choice: tiles of the Morton-key sort up to which 3 x 10-bit passes beat 4 x 8-bit (measured: 85 vs 93 us at
 // 245 tiles, 420 vs 300 us at 2444 -- the 1024-digit tables and 16-byte runs cost more than the saved pass)
 constexpr uint32_t kSort3PassMaxTiles = 512;

@@ -185,6 +185,15 @@ int rt_generate_morton_codes(uint32_t* codes, uint32_t* values, const rt_triangl
 size_t rt_radix_sort_scratch_bytes(uint32_t count);
 int rt_radix_sort_u32_pairs(uint32_t* keys, uint32_t* values, uint32_t* tmp_keys, uint32_t* tmp_values,
                             uint32_t count, void* sort_scratch, void* stream);
+/* The same sort for keys whose bits [key_bits, 32) are all zero (RunBottomUpBuild's Morton codes have 30,
+ * BottomUpBuilder.cu:23-32; the reference's RadixSort always runs its four 8-bit passes, RadixSort.cu:192-219).
+ * Up to 30 bits and a moderate count it runs three 10-bit passes, which read their input from the temporaries:
+ * input_in_tmp = 1 says the unsorted pairs are in tmp_keys / tmp_values (0: in keys / values); when that is not where
+ * the chosen pass count reads from, the pairs are copied across first (rt_radix_sort_input_in_tmp tells a caller that
+ * wants to avoid the copy where to put them).  The sorted result is in keys / values either way. */
+int rt_radix_sort_u32_pairs_bits(uint32_t* keys, uint32_t* values, uint32_t* tmp_keys, uint32_t* tmp_values,
+                                 uint32_t count, uint32_t key_bits, int input_in_tmp, void* sort_scratch, void* stream);
+int rt_radix_sort_input_in_tmp(uint32_t count, uint32_t key_bits);
 
 /* replaces Trace()/TraceRays (main.cu:125-192, Tracer.cu:471-595) for rows [y0, y1) of a w x h frame.
  * rgba8: full-frame linear RGBA8 buffer, pitch 4*w, row 0 first (= the surface contents, SURVEY A).

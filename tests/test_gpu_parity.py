@@ -444,3 +444,34 @@ def test_lbvh_build_stress_back_to_back(rt, scenes, ora):
         bad += (got_n != exp_nodes[k]).any().to(torch.int64) + (got_l != exp_leaves[k]).any().to(torch.int64)
     torch.cuda.synchronize()
     assert int(bad.item()) == 0, f"{int(bad.item())} of 600 builds differ from the oracle"
+
+
+@pytest.mark.parametrize("poison", [0xCD, 0xFF, 0x00])
+@pytest.mark.parametrize("variant", ["bottom-up", "hybrid", "pairs"])
+def test_build_is_independent_of_stale_scratch(rt, scenes, ora, poison, variant):
+    """The caller's scratch is uninitialised memory (torch.empty here, cudaMalloc in main.cu:231-237): every word the build
+    reads from it must have been written earlier in the SAME build.  The scratch (and the outputs) are filled with a
+    poison byte before each build; the result must not change.  (Round 2's unexplained GPU fault, gpurun_out/r2l, was
+    an uncommitted experiment -- DESIGN section 5 -- but this is the class of defect it would have been in shipped code;
+    the kernels also range-check every address they form from a scratch word, status bits 1 and 2.)"""
+    import torch
+    from helpers import assert_nodes_equal
+    pairs, hybrid = variant == "pairs", variant == "hybrid"
+    args = rt.Arguments(build_type=rt.kHybrid if hybrid else rt.kBottomUp, enable_pairs=pairs)
+    for tris in (scenes.grid_mesh(24, 1), scenes.soup(70001, 5), scenes.grid_mesh(120, 2)):
+        n = tris.shape[0]
+        inp = rt.BuildInput.allocate(tris)
+        inp.scratch.fill_(poison)
+        inp.triangles_out.fill_(poison)
+        inp.nodes_out.fill_(0 if hybrid else poison)   # (slots the hybrid top tree never writes stay as they were)
+        rt.RunBottomUpBuild(inp, args, hybrid=hybrid)
+        torch.cuda.synchronize()
+        lay = rt.scratch_layout(n)
+        status = rt.to_host(inp.scratch, np.uint32, 8, lay.status)
+        assert status[0] == 0, f"error flags {status[0]:#x}"
+        L = int(status[1])
+        o = ora.build_pairs(tris) if pairs else (ora.build_hybrid(tris) if hybrid else ora.build_bvh(tris))
+        assert L == o["leaves"].shape[0]
+        what = f"{variant} n={n} poison={poison:#x}"
+        assert_nodes_equal(rt.to_host(inp.nodes_out, rt.NODE, o["nodes"].shape[0]), o["nodes"], what)
+        assert rt.to_host(inp.triangles_out, rt.TRIANGLE_PAIR, L).tobytes() == o["leaves"].tobytes(), what
