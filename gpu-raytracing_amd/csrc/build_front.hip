@@ -185,40 +185,42 @@ __global__ __launch_bounds__(256) void morton_kernel(uint32_t* __restrict__ code
     values[gid] = gid;
 }
 
-// Morton codes + the group histograms of the sort's first pass in one launch: a workgroup owns one group of sort tiles
+// Morton codes + the tile histograms of the sort's first pass in one launch: a workgroup owns TQ sort tiles
 // (4096 triangles each: every lane reads its 36-byte triangle directly -- neighbouring lanes use the rest of every
-// line) and counts the low BITS bits of its codes in LDS exactly as sort_upsweep_kernel would.  values == nullptr: the
-// identity values[i] = i (BottomUpBuilder.cu:113) is not written; the sort's first pass regenerates it.
-template <uint32_t BITS, uint32_t NT>
+// line) and counts the low BITS bits of its codes in LDS exactly as sort_upsweep_kernel would (same table layout: rows
+// of `stride` words, TQ = 4 publishes 16 bytes per digit).  values == nullptr: the identity values[i] = i
+// (BottomUpBuilder.cu:113) is not written; the sort's first pass regenerates it.
+template <uint32_t BITS, uint32_t NT, uint32_t TQ>
 __global__ __launch_bounds__(NT) void morton_hist_kernel(uint32_t* __restrict__ codes, uint32_t* __restrict__ values,
                                                           const float* __restrict__ f, const int* __restrict__ aabb,
                                                           uint32_t n, uint32_t nparts, int* __restrict__ aabb_out,
-                                                          uint32_t* __restrict__ hist, uint32_t num_tiles, uint32_t tpw)
+                                                          uint32_t* __restrict__ hist, uint32_t stride)
 {
     constexpr uint32_t RADIX = 1u << BITS;
-    __shared__ uint32_t h[RADIX];
+    static_assert(TQ == 1 || TQ == 4, "one dword or one uint4 per digit");
+    __shared__ uint32_t h[TQ][RADIX];
     __shared__ int sbox[6];
     float bmin[3], bmax[3];
-    for (uint32_t d = threadIdx.x; d < RADIX; d += NT) h[d] = 0;
+    for (uint32_t d = threadIdx.x; d < RADIX * TQ; d += NT) (&h[0][0])[d] = 0;
     fold_scene_box(aabb, nparts, sbox, bmin, bmax);   // (its barriers also order the zeroing of h)
     if (aabb_out && blockIdx.x == 0 && threadIdx.x < 6) aabb_out[threadIdx.x] = sbox[threadIdx.x];
-    const uint32_t group = blockIdx.x, num_groups = gridDim.x;
-    const uint32_t t0 = group * tpw, t1 = min(t0 + tpw, num_tiles);
+    const uint32_t tile0 = blockIdx.x * TQ;
     const int lane = threadIdx.x & 63;
     const float minx = bmin[0], miny = bmin[1], minz = bmin[2], maxx = bmax[0], maxy = bmax[1], maxz = bmax[2];
-    for (uint32_t tile = t0; tile < t1; tile++) {
-        const uint32_t base = tile * kSortTile;
+    for (uint32_t t = 0; t < TQ; t++) {
+        const uint32_t base = (tile0 + t) * kSortTile;
+        if (base >= n) break;
 #pragma unroll 4
         for (uint32_t i = 0; i < kSortTile / NT; i++) {
             const uint32_t gid = base + i * NT + threadIdx.x;
             const bool valid = gid < n;
             uint32_t code = 0;
             if (valid) {
-                float t[9];
-                load_tri9(f + (size_t)gid * 9, t);
-                float cx = ((t[0] + t[3]) + t[6]) / 3.0f;
-                float cy = ((t[1] + t[4]) + t[7]) / 3.0f;
-                float cz = ((t[2] + t[5]) + t[8]) / 3.0f;
+                float tr[9];
+                load_tri9(f + (size_t)gid * 9, tr);
+                float cx = ((tr[0] + tr[3]) + tr[6]) / 3.0f;
+                float cy = ((tr[1] + tr[4]) + tr[7]) / 3.0f;
+                float cz = ((tr[2] + tr[5]) + tr[8]) / 3.0f;
                 cx = (cx - minx) / (maxx - minx);
                 cy = (cy - miny) / (maxy - miny);
                 cz = (cz - minz) / (maxz - minz);
@@ -233,14 +235,17 @@ __global__ __launch_bounds__(NT) void morton_hist_kernel(uint32_t* __restrict__ 
             const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
             if (__popcll(__ballot(valid && d == d0)) >= 8) {
                 const uint64_t m = match_digit<BITS>(d, valid);
-                if (valid && lane == __ffsll((unsigned long long)m) - 1) atomicAdd(&h[d], (uint32_t)__popcll(m));
+                if (valid && lane == __ffsll((unsigned long long)m) - 1) atomicAdd(&h[t][d], (uint32_t)__popcll(m));
             } else if (valid) {
-                atomicAdd(&h[d], 1u);
+                atomicAdd(&h[t][d], 1u);
             }
         }
     }
     __syncthreads();
-    for (uint32_t d = threadIdx.x; d < RADIX; d += NT) hist[(size_t)d * num_groups + group] = h[d];
+    for (uint32_t d = threadIdx.x; d < RADIX; d += NT) {
+        if (TQ == 4) *reinterpret_cast<uint4*>(hist + (size_t)d * stride + tile0) = make_uint4(h[0][d], h[1 % TQ][d], h[2 % TQ][d], h[3 % TQ][d]);
+        else hist[(size_t)d * stride + tile0] = h[0][d];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -411,14 +416,19 @@ hipError_t launch_morton_hist(uint32_t* codes, uint32_t* values, const rt_triang
                               hipStream_t st, uint32_t nparts, int* aabb_out, uint32_t* hist, uint32_t bits)
 {
     if (n == 0) return hipSuccess;
-    const uint32_t tiles = sort_num_tiles(n);
-    const uint32_t tpw = sort_tiles_per_group(tiles), groups = (tiles + tpw - 1) / tpw;   // the sort's own grouping
+    const uint32_t tiles = sort_num_tiles(n), stride = sort_table_stride(tiles);
     const float* f = reinterpret_cast<const float*>(tris);
-    // few tiles (the 3 x 10-bit regime): 1024 threads per tile (4 triangles each) -- a pass over 245 tiles is one workgroup's chain
-    if (bits == 10)
-        morton_hist_kernel<10, 1024><<<groups, 1024, 0, st>>>(codes, values, f, aabb, n, nparts ? nparts : 1u, aabb_out, hist, tiles, tpw);
-    else
-        morton_hist_kernel<8, 256><<<groups, 256, 0, st>>>(codes, values, f, aabb, n, nparts ? nparts : 1u, aabb_out, hist, tiles, tpw);
+    const uint32_t np = nparts ? nparts : 1u;
+    // few tiles: 1024 threads per tile (4 triangles each) -- a pass over 245 tiles is one workgroup's chain; many: 256
+    // threads per tile (four tiles per workgroup, as the sort's own histogram kernel does, was measured slower here: 83 vs
+    // 77 us at 10M -- this kernel is bound by the 36-byte triangle reads, not by its table writes)
+    if (sort_upsweep_quads(tiles)) {
+        if (bits == 10) morton_hist_kernel<10, 256, 1><<<tiles, 256, 0, st>>>(codes, values, f, aabb, n, np, aabb_out, hist, stride);
+        else morton_hist_kernel<8, 256, 1><<<tiles, 256, 0, st>>>(codes, values, f, aabb, n, np, aabb_out, hist, stride);
+    } else {
+        if (bits == 10) morton_hist_kernel<10, 1024, 1><<<tiles, 1024, 0, st>>>(codes, values, f, aabb, n, np, aabb_out, hist, stride);
+        else morton_hist_kernel<8, 1024, 1><<<tiles, 1024, 0, st>>>(codes, values, f, aabb, n, np, aabb_out, hist, stride);
+    }
     return hipGetLastError();
 }
 

@@ -66,15 +66,18 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
     return (uint32_t)(__builtin_amdgcn_readlane(s, 0) + __builtin_amdgcn_readlane(s, 16) +
                       __builtin_amdgcn_readlane(s, 32) + __builtin_amdgcn_readlane(s, 48));
 }
-// inclusive scan across the 64 lanes of a wave
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
+// inclusive scan across the 64 lanes of a wave with DPP row shifts / row broadcasts: VALU only (a __shfl_up ladder goes
+// through the LDS crossbar: six dependent ds_bpermute round trips).  All 64 lanes must be active at the call.
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int /*lane*/ = 0)
 {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t t = __shfl_up(v, o, 64);
-        if (lane >= o) v += t;
-    }
-    return v;
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);   // row_shr:8  -> inclusive inside each row of 16
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
+    return (uint32_t)x;
 }
 
 // Workgroups are dealt to the 8 XCDs round-robin (b -> XCD b % 8; observed, speed only -- MI355X_MICROARCH.md, dispatch):

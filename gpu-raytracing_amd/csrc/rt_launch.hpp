@@ -40,6 +40,11 @@ constexpr uint32_t kSortPasses = 4;
 constexpr uint32_t kRadixMax = 1024;   // the 10-bit passes of the Morton-key sort; tables are sized for it
 
 inline uint32_t sort_num_tiles(uint32_t n) { return (n + kSortTile - 1) / kSortTile; }
+// the sort's tables hold one word per (digit, tile); a row is padded to a multiple of 4 words (one aligned 16-byte access
+// covers four tiles)
+inline uint32_t sort_table_stride(uint32_t tiles) { return tiles ? (tiles + 3u) & ~3u : 4u; }
+// many tiles: the histogram kernels take four tiles per workgroup and publish 16 bytes per digit
+inline bool sort_upsweep_quads(uint32_t tiles) { return tiles > 512; }
 
 struct SortScratch {
     size_t digit_total;  // uint32[kSortPasses][kRadixMax]
@@ -124,13 +129,12 @@ hipError_t launch_morton_pairs(uint32_t* codes, uint32_t* values, const rt_trian
 // n_dev (may be null): device word holding the real element count (<= n); n then only sizes the grids.
 // key_bits <= 30 (Morton keys): 3 passes of 10 bits, and the INPUT is taken from (tmp_keys, tmp_vals); the sorted result
 // is in (keys, vals) either way.
-// have_hist0: the first pass's group histograms are already in the sort scratch (launch_morton_hist wrote them).
+// have_hist0: the first pass's tile histograms are already in the sort scratch (launch_morton_hist wrote them).
 // ident0: the input values are the identity (values[i] = i) and are not read.
 hipError_t launch_radix_sort(uint32_t* keys, uint32_t* vals, uint32_t* tmp_keys, uint32_t* tmp_vals, uint32_t n,
                              void* sort_scratch, hipStream_t st, const uint32_t* n_dev = nullptr, uint32_t key_bits = 32,
                              bool have_hist0 = false, bool ident0 = false);
 bool sort_three_passes(uint32_t tiles);          // keys of <= 30 bits: 3 x 10-bit passes (else 4 x 8)
-uint32_t sort_tiles_per_group(uint32_t tiles);   // consecutive tiles one workgroup works through
 // the builder's choice: tiles of the Morton-key sort up to which 3 x 10-bit passes beat 4 x 8-bit (measured: 85 vs 93 us at
 // 245 tiles, 420 vs 300 us at 2444 -- the 1024-digit tables and 16-byte runs cost more than the saved pass)
 constexpr uint32_t kSort3PassMaxTiles = 512;

@@ -7,11 +7,8 @@
 #include "MemoryBuffer.h"
 #include "RadixSort.h"
 
-void Trace(const TrianglePair* triangles, const Node* nodes, uint8_t* rgba8, int dims_x, int dims_y, const Camera* camera_dev,
-           unsigned root, unsigned count, RenderType render_type, const DeviceSceneView& scene, uint64_t* num_tests,
-           unsigned y0, unsigned y1, unsigned spp, void* stream)
+static rt_scene SceneOf(const DeviceSceneView& scene, const Camera* camera_dev)
 {
-    rt_accel as{triangles, nodes, root, count};
     rt_scene sc{};
     sc.attributes = scene.attributes;
     sc.materials = scene.materials;
@@ -21,9 +18,32 @@ void Trace(const TrianglePair* triangles, const Node* nodes, uint8_t* rgba8, int
     sc.num_materials = scene.num_materials;
     sc.textures = scene.textures;
     sc.num_textures = scene.num_textures;
+    return sc;
+}
+
+void Trace(const TrianglePair* triangles, const Node* nodes, uint8_t* rgba8, int dims_x, int dims_y, const Camera* camera_dev,
+           unsigned root, unsigned count, RenderType render_type, const DeviceSceneView& scene, uint64_t* num_tests,
+           unsigned y0, unsigned y1, unsigned spp, void* stream)
+{
+    rt_accel as{triangles, nodes, root, count};
+    const rt_scene sc = SceneOf(scene, camera_dev);
     const int rc = rt_trace(&as, &sc, num_tests, (int)render_type, rgba8, (uint32_t)dims_x, (uint32_t)dims_y, y0, y1, spp, stream);
     if (rc != RT_OK) {
         fprintf(stderr, "gpu_assert: Trace: %s (%d)\n", rt_error_string(rc), rc);
+        exit(rc < 0 ? -rc : rc);
+    }
+}
+
+void TraceStrips(const TrianglePair* triangles, const Node* nodes, uint8_t* rgba8_compact, int dims_x, int dims_y,
+                 const Camera* camera_dev, unsigned root, unsigned count, RenderType render_type, const DeviceSceneView& scene,
+                 uint64_t* num_tests, unsigned strip_rows, unsigned first_strip, unsigned strip_stride, unsigned spp, void* stream)
+{
+    rt_accel as{triangles, nodes, root, count};
+    const rt_scene sc = SceneOf(scene, camera_dev);
+    const int rc = rt_trace_strips(&as, &sc, num_tests, (int)render_type, rgba8_compact, (uint32_t)dims_x, (uint32_t)dims_y,
+                                   strip_rows, first_strip, strip_stride, spp, stream);
+    if (rc != RT_OK) {
+        fprintf(stderr, "gpu_assert: TraceStrips: %s (%d)\n", rt_error_string(rc), rc);
         exit(rc < 0 ? -rc : rc);
     }
 }

@@ -31,3 +31,10 @@ private:
 void Trace(const TrianglePair* triangles, const Node* nodes, uint8_t* rgba8, int dims_x, int dims_y, const Camera* camera_dev,
            unsigned root, unsigned count, RenderType render_type, const DeviceSceneView& scene, uint64_t* num_tests,
            unsigned y0, unsigned y1, unsigned spp = 1, void* stream = nullptr);
+
+// The interleaved-strip form of the same frame (rt_trace_strips; multi-GPU partition, Partition.h): strips first_strip,
+// first_strip + strip_stride, ... rendered in ONE launch and stored compactly in rgba8_compact.
+void TraceStrips(const TrianglePair* triangles, const Node* nodes, uint8_t* rgba8_compact, int dims_x, int dims_y,
+                 const Camera* camera_dev, unsigned root, unsigned count, RenderType render_type, const DeviceSceneView& scene,
+                 uint64_t* num_tests, unsigned strip_rows, unsigned first_strip, unsigned strip_stride, unsigned spp = 1,
+                 void* stream = nullptr);
