@@ -153,7 +153,7 @@ void MultiGpuTracer::TraceFrame(const Camera& camera, RenderType render_type, un
     const unsigned P = (unsigned)dev_.size(), W = (unsigned)width_, H = (unsigned)height_;
     Partition use = partition;
     if (partition == Partition::kAuto) use = decided_ == Partition::kAuto ? Partition::kBands : decided_;
-    if (P == 1) use = Partition::kBands;
+    if (P == 1 && partition == Partition::kAuto) use = Partition::kBands;   // (explicit strips on one device: the same code path, de-interleave = identity)
     last_partition_ = use;
     const size_t row = (size_t)W * 4;
     const unsigned J = StripsPerDevice(H, P);

@@ -5,7 +5,11 @@
 //
 //   rt_cli <file.obj> [--type sah|bottom-up|hybrid] [--pairs] [--splits] [--render depth|boxtests|tritests|material|lods|diffuse|texture|texturelit|shadows]
 //          [--width W] [--height H] [--spp N] [--yaw Y --pitch P --pos X Y Z] [--out frame.ppm] [--frames K]
-//          [--path "<ev>,<ev>,..."] [--rebuild]
+//          [--path "<ev>,<ev>,..."] [--rebuild] [--gpus N [--partition bands|strips|auto]]
+//
+// --gpus N: the frame is traced by N GPUs of this node from this ONE process (MultiGpu.h): replicated build per device,
+// one row band (or interleaved strips) per device, one grouped RCCL send/recv per frame into device 0, counters summed by
+// ncclReduce.  --gpus 1 takes the same code path with a one-device communicator.
 //
 // --path: one comma-separated entry per frame (repeated cyclically when shorter than --frames); an entry is a
 // concatenation of events applied BEFORE that frame is traced, in the order the GLUT callbacks would have run:
@@ -30,6 +34,7 @@
 #include "Camera.h"
 #include "FileIO.h"
 #include "MemoryBuffer.h"
+#include "MultiGpu.h"
 #include "Tracer.h"
 #include "Utilities.h"
 
@@ -46,6 +51,71 @@ static RenderType ParseRender(const std::string& s)
     return kDepth;
 }
 
+// --gpus N: Display() with the frame partitioned across N devices (static camera; the scripted input path and --rebuild
+// belong to the single-device loop below)
+static int RunMultiGpu(int gpus, Partition partition, const Scene& scene, const Arguments& args, const Camera& camera, int width,
+                       int height, int frames, unsigned spp, const std::string& out)
+{
+    const unsigned n = (unsigned)scene.triangles.size();
+    const bool hybrid = args.build_type == kHybrid, sah = args.build_type == kSAH;
+    MultiGpuTracer mg(gpus);
+    mg.UploadScene(scene);
+    const float build_ms = mg.Build(args);
+    printf("%s time elapsed: %fms (%d replica%s, slowest)\n", sah ? "RunSahBuild" : "RunBottomUpBuild", build_ms, gpus, gpus == 1 ? "" : "s");
+    // frame 0 of Display() on replica 0: status, number of leaves, read back, count, verify (main.cu:248-259)
+    const BuildInput& in = mg.Replica0();
+    size_t num_leaves_off, status_off;
+    if (sah) { rt_sah_scratch_layout lay; rt_sah_scratch_layout_get(n, &lay); num_leaves_off = lay.num_leaves; status_off = lay.status; }
+    else { rt_bu_scratch_layout lay; rt_bu_scratch_layout_get(n, &lay); num_leaves_off = lay.num_leaves; status_off = lay.status; }
+    unsigned num_leaves = n, build_status = 0;
+    check(hipSetDevice(0));
+    check(hipMemcpy(&num_leaves, static_cast<char*>(in.scratch) + num_leaves_off, 4, hipMemcpyDeviceToHost));
+    check(hipMemcpy(&build_status, static_cast<char*>(in.scratch) + status_off, 4, hipMemcpyDeviceToHost));
+    if (build_status != 0) {
+        fprintf(stderr, "gpu_assert: %s reported error flags 0x%x (incomplete tree)\n", sah ? "RunSahBuild" : "RunBottomUpBuild", build_status);
+        return 3;
+    }
+    const unsigned root_count = sah ? 1 : 2;
+    const unsigned root_index = hybrid ? (num_leaves * 2 > 2 ? num_leaves * 2 : 2) + 1 : 0;
+    std::vector<Node> nodes(sah ? ((size_t)n + n / 5) * 2 + 130 : (size_t)(n ? n : 1) * 4);
+    check(hipMemcpy(nodes.data(), in.nodes_out, sizeof(Node) * nodes.size(), hipMemcpyDeviceToHost));
+    const HierarchyStats hs = CountNodes(nodes.data(), root_index, root_count);
+    printf("Hierarchy Stats:\n  num nodes: %d\n  num tree nodes: %d\n  num leaf nodes: %d\n", hs.numNodes, hs.numTreeNodes, hs.numLeafNodes);
+    const int bad = VerifyHierarchy(nodes.data(), root_index, root_count);
+
+    mg.Resize(width, height);
+    uint64_t tests[4] = {0, 0, 0, 0};
+    double total_ms = 0;
+    for (int f = 0; f < frames; f++) {
+        const auto t0 = std::chrono::steady_clock::now();
+        mg.TraceFrame(camera, args.render_type, root_index, root_count, spp, partition);
+        (void)mg.Frame();                                                   // the gathered frame is on device 0
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        total_ms += ms;
+        mg.Counters(tests);
+        const std::vector<float>& dms = mg.DeviceMs();
+        if (f == 0) {
+            printf("TraceRays time elapsed: %fms (host clock, %d device%s, gather included)\n", ms, gpus, gpus == 1 ? "" : "s");
+            printf("TraceRays number of tests %llu\n", (unsigned long long)tests[0]);   // main.cu:180-183
+        }
+        printf("frame %d: %s  %.3f ms  box tests %llu  triangle tests %llu  %.1f Mrays/s  per-device trace ms:", f,
+               mg.LastPartition() == Partition::kStrips ? "strips" : "bands", ms, (unsigned long long)tests[0],
+               (unsigned long long)tests[1], (double)width * height * spp / ms / 1e3);
+        for (float v : dms) printf(" %.3f", v);
+        printf("\n");
+    }
+    if (frames > 1) printf("%d frames: mean %fms = %.1f fps\n", frames, total_ms / frames, 1e3 * frames / total_ms);
+    if (!out.empty()) {
+        std::vector<uint8_t> frame;
+        mg.FrameToHost(frame);
+        std::ofstream os(out, std::ios::binary);
+        os << "P6\n" << width << " " << height << "\n255\n";
+        for (size_t p = 0; p < (size_t)width * height; p++) os.write(reinterpret_cast<const char*>(&frame[p * 4]), 3);
+        printf("wrote %s\n", out.c_str());
+    }
+    return bad ? 1 : 0;
+}
+
 int main(int argc, char** argv)
 {
     if (argc < 2) {
@@ -58,6 +128,8 @@ int main(int argc, char** argv)
     unsigned spp = 1;
     std::string out, path;
     bool rebuild = false;
+    int gpus = 0;                                              // 0: the single-device path of the reference
+    Partition partition = Partition::kAuto;
     bool have_pos = false, have_yaw = false, have_pitch = false;
     vec3 pos{0, 0, 0};
     float yaw = 0, pitch = 0;
@@ -72,6 +144,12 @@ int main(int argc, char** argv)
         else if (a == "--out") { out = next(1); i++; }
         else if (a == "--path") { path = next(1); i++; }
         else if (a == "--rebuild") { rebuild = true; }
+        else if (a == "--gpus") { gpus = atoi(next(1)); i++; }
+        else if (a == "--partition") {
+            const std::string v = next(1);
+            partition = v == "bands" ? Partition::kBands : (v == "strips" ? Partition::kStrips : Partition::kAuto);
+            i++;
+        }
         else if (a == "--yaw") { yaw = (float)atof(next(1)); have_yaw = true; i++; }
         else if (a == "--pitch") { pitch = (float)atof(next(1)); have_pitch = true; i++; }
         else if (a == "--pos") { pos = make_vec3((float)atof(next(1)), (float)atof(next(2)), (float)atof(next(3))); have_pos = true; i += 3; }
@@ -90,6 +168,8 @@ int main(int argc, char** argv)
     if (have_pitch) camera[0].pitch = pitch;
     UpdateCamera(camera[0]);
     camera.toDevice();
+
+    if (gpus > 0) return RunMultiGpu(gpus, partition, scene, args, camera[0], width, height, frames, spp, out);
 
     // frame 0 of Display(): the four device buffers, upload, build, read back, count, verify (main.cu:226-259)
     BuildInput in{};

@@ -227,3 +227,39 @@ def test_rt_cli_rebuild_every_frame(tmp_path, rt, ora):
         assert p.returncode == 0, p.stderr
         res.append(re.findall(r"frame (\d+): TraceRays \S+ms  box tests (\d+)  triangle tests (\d+)", p.stdout))
     assert len(res[0]) == 4 and res[0] == res[1]
+
+
+@pytest.mark.parametrize("partition", ["bands", "strips", "auto"])
+@pytest.mark.parametrize("build_type", ["bottom-up", "sah"])
+def test_rt_cli_multi_gpu_host_path(tmp_path, rt, ora, partition, build_type):
+    """host/MultiGpu.cpp, the one-process multi-device Trace() (replicated build, one band or strip set per device, grouped RCCL
+    send/recv into device 0, ncclReduce of the test counters): `rt_cli --gpus 1` builds a ONE-device RCCL communicator and
+    takes exactly that path.  The frame and the counters must equal the single-device path's (and the oracle's).  More than
+    one device is unmeasured in this environment (one GPU per box): the partition arithmetic for 1 - 8 devices is unit-tested
+    on the CPU (tests/test_host_mirror.py)."""
+    host = importlib.import_module("gpu-raytracing_amd.host_py")
+    cli = os.path.join(ROOT, "gpu-raytracing_amd", "host", "rt_cli")
+    obj = os.path.join(GOLD, "cornell34.obj")
+    outs = {}
+    for tag, extra in (("single", []), ("multi", ["--gpus", "1", "--partition", partition])):
+        out = str(tmp_path / f"{tag}.ppm")
+        p = subprocess.run([cli, obj, "--type", build_type, "--render", "diffuse", "--width", "322", "--height", "203",
+                            "--pos", "5", "5", "-5.25", "--yaw", "0", "--pitch", "0", "--out", out, "--frames", "1"] + extra,
+                           capture_output=True, text=True, timeout=180)
+        assert p.returncode == 0, p.stderr + p.stdout
+        assert "Invalid hierarchy" not in p.stderr
+        outs[tag] = (open(out, "rb").read(), int(re.search(r"TraceRays number of tests (\d+)", p.stdout).group(1)), p.stdout)
+    assert outs["multi"][0] == outs["single"][0], "frame of the multi-device path differs from the single-device path"
+    assert outs["multi"][1] == outs["single"][1], "summed box tests differ"
+    assert ("strips" if partition == "strips" else "bands") in outs["multi"][2]
+    s = host.LoadOBJFromFile(obj)
+    cam = host.InitialiseCamera(s["aabb"])
+    cam["position"], cam["yaw"], cam["pitch"] = [5, 5, -5.25], 0, 0
+    cam = host.UpdateCamera(cam)
+    o = {"bottom-up": ora.build_bvh, "sah": ora.build_sah}[build_type](s["triangles"])
+    exp, cnt = ora.trace(o["leaves"], o["nodes"], o.get("root", 0), o.get("count", 2), cam, 322, 203, render_type=5,
+                         attributes=s["attributes"], materials=s["materials"], light=tuple(s["light"]))
+    assert outs["multi"][1] == int(cnt[0])
+    hdr = b"P6\n322 203\n255\n"
+    got = np.frombuffer(outs["multi"][0][len(hdr):], np.uint8).reshape(203, 322, 3)
+    assert (got == exp[..., :3]).all()

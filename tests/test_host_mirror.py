@@ -161,3 +161,39 @@ def test_parse_cmd_matches_the_reference_code(ora):
         out = (ctypes.c_int * 4)()
         H.rth_parse_cmd(len(argv), arr, out)
         assert tuple(out) == tuple(int(v) for v in ora.ref_parse_cmd(argv)), argv
+
+
+def test_partition_arithmetic_matches_the_python_harness():
+    """host/Partition.h (the C++ multi-device path's frame partition, 1 - 8 devices) against gpu-raytracing_amd/sharding.py
+    (what bench.py and the gloo tests use): row bands, interleaved strips, the bands -> strips decision."""
+    import ctypes
+    import importlib
+    sh = importlib.import_module("gpu-raytracing_amd.sharding")
+    L = _hostlib()
+    out2 = (ctypes.c_uint * 2)()
+    for fn in (L.rth_num_strips, L.rth_strips_per_device, L.rth_strips_owned, L.rth_compact_rows, L.rth_strip_rows_in_frame):
+        fn.restype = ctypes.c_uint
+    L.rth_choose_partition.restype = ctypes.c_int
+    L.rth_choose_partition.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_uint]
+    for height in (1, 7, 8, 9, 53, 768, 1080, 1081, 2160):
+        assert L.rth_num_strips(height) == sh.num_strips(height)
+        for world in range(1, 9):
+            b = sh.band_bounds(height, world)
+            covered = 0
+            for d in range(world):
+                L.rth_band_of(height, world, d, out2)
+                assert (out2[0], out2[1]) == (b[d], b[d + 1])
+                covered += out2[1] - out2[0]
+                assert L.rth_strips_owned(height, world, d) == len(sh.my_strips(height, world, d))
+            assert covered == height
+            assert L.rth_strips_per_device(height, world) == sh.strips_per_rank(height, world)
+            assert L.rth_compact_rows(height, world) == sh.compact_rows(height, world)
+            # every row of the frame lies in exactly one strip of exactly one device
+            rows = 0
+            for d in range(world):
+                for s in sh.my_strips(height, world, d):
+                    rows += L.rth_strip_rows_in_frame(height, s)
+            assert rows == height
+    for costs in ([1.0], [1.0, 1.0], [0.02, 0.02, 0.85, 0.31], [1.0, 1.1, 1.0, 1.05], [0.0, 0.0], [1.0, 1.16, 1.0, 0.84]):
+        arr = (ctypes.c_double * len(costs))(*costs)
+        assert ("bands", "strips")[L.rth_choose_partition(arr, len(costs))] == sh.choose_partition(costs)
