@@ -203,6 +203,34 @@ def main():
             times.append(e0.elapsed_time(e1))
         build_ms = statistics.median(times)
 
+    # ---- the build's radix sort on its own (the stage entry points of the C ABI): the scene's Morton codes, sorted on 30
+    # bits exactly as the builder does; HIP events around the sort alone, input restored (untimed) before every run
+    sort_us = None
+    if not args.no_extras and args.type == "bottom-up" and world == 1 and n > 0:
+        import numpy as np  # noqa: PLC0415
+        d_aabb = torch.zeros(8, dtype=torch.int32, device="cuda")
+        k0 = torch.empty(n, dtype=torch.int32, device="cuda")
+        v0 = torch.empty_like(k0)
+        rt.CalculateSceneAabb(inp.triangles_in, n, d_aabb)
+        rt.GenerateMortonCodes(k0, v0, inp.triangles_in, d_aabb, n)
+        kk, vv, tk, tv = (torch.empty_like(k0) for _ in range(4))
+        scr = rt.device_bytes(rt.RadixSortScratchBytes(n))
+        in_tmp = bool(rt.lib().rt_radix_sort_input_in_tmp(n, 30))
+        ts = []
+        for it in range(13):
+            (tk if in_tmp else kk).copy_(k0)
+            (tv if in_tmp else vv).copy_(v0)
+            e0, e1 = ev(), ev()
+            e0.record()
+            rt.RadixSortBits(kk, vv, tk, tv, n, 30, input_in_tmp=in_tmp, sort_scratch=scr)
+            e1.record()
+            e1.synchronize()
+            if it >= 3:
+                ts.append(e0.elapsed_time(e1) * 1e3)
+        sort_us = statistics.median(ts)
+        assert bool((kk[1:] >= kk[:-1]).all()), "sorted Morton codes are not ascending"
+        del k0, v0, kk, vv, tk, tv, scr
+
     cams = {"a": scenes.camera_a(G), "b": scenes.camera_b(G)}
     cam_dev = {k: rt.to_device(v) for k, v in cams.items()}
     cam = args.camera
@@ -412,6 +440,7 @@ def main():
             "build_ms": round(build_ms, 4),
             "build_gbps_algorithmic": round(512.0 * n / (build_ms * 1e-3) / 1e9, 1),  # 512 B/triangle, SURVEY 8(d)
             "build_frac_of_hbm_peak": round(512.0 * n / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "build": build_record(n, build_ms, sort_us, args.type, G),
         }
     if not args.no_extras and args.type == "bottom-up" and world == 1:
         # the SAH builder (the reference's default --type) on the same triangles: build time only here, so that every
@@ -480,12 +509,12 @@ def main():
         # pass cannot run inside this process, so the figure is the committed result of `tools/pmc_trace.sh` on this same
         # command; it is attached only to the exact workload it was collected on and labelled with its source.
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "trace_traffic.json")
-        if os.path.exists(tpath) and world == 1 and cam == "a" and (W, H, G, args.spp) == (1920, 1080, 708, 1) and args.type == "bottom-up":
+        tpath = os.path.join(ROOT, "profiles", "trace_traffic.json" if G == 708 else "trace_traffic_10m.json")
+        if os.path.exists(tpath) and world == 1 and cam == "a" and (W, H, args.spp) == (1920, 1080, 1) and G in (708, 2237) and args.type == "bottom-up":
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get("hbm_bytes_per_launch")
-                traffic_src = f"profiles/trace_traffic.json ({tj.get('source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command')})"
+                traffic_src = f"profiles/{os.path.basename(tpath)} ({tj.get('source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command')})"
             except Exception:
                 traffic = None
         roof = {
@@ -494,7 +523,14 @@ def main():
             # on the GPU; peak = 256 CUs x 64 B/clk x 2.4 GHz of L1 data path.
             "bound": "l1", "kernel": "trace_kernel", "achieved": round(serial_l1, 1), "peak": round(L1_PEAK_GBS, 1),
             "unit": "GB/s", "frac": round(serial_l1 / L1_PEAK_GBS, 4),
-            "peak_formula": "256 CUs x 64 B/clk x 2.4 GHz (vector L1 data path)",
+            "peak_formula": "256 CUs x 64 B/clk x 2.4 GHz (vector L1 data path) -- a NOMINAL figure: MI355X_MICROARCH.md does not "
+                            "state it; the measured ceilings of this access pattern are in measured_ceilings",
+            "measured_ceilings": {"divergent_16B_gather_this_repo_GBps": round(GATHER_CEILING_GBS, 1),
+                                  "divergent_16B_gather_source": "tools/ta_microbench.hip, profiles/r02_ta_microbench.txt (0.69 clk per lane request)",
+                                  "l2_served_row_gather_guide_GBps": [16800, 18800],
+                                  "l2_served_row_gather_source": "MI355X_MICROARCH.md, 'Indexed rows: gather into LDS' (2,048 rows shared by every workgroup)",
+                                  "frac_of_divergent_gather": round(serial_l1 / GATHER_CEILING_GBS, 4),
+                                  "frac_of_guide_l2_gather_low": round(serial_l1 / 16800.0, 4)},
             "algorithmic_bytes_per_launch": alg_bytes, "formula": "32*sum(box_tests) + 64*sum(tri_tests) + 4*W*rows",
             "kernel_ms": round(serial_ms, 4),
             "kernel_ms_is": f"median of 22 serial launches of this rank's part, HIP events on the launch stream "
@@ -508,9 +544,11 @@ def main():
             "algorithmic_over_hbm_peak_is": "> 1 means cache reuse: these bytes cannot all have come from HBM",
             "traffic": traffic, "traffic_source": traffic_src,
             "hbm_counter_frac": (round(traffic / (serial_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None),
-            "north_star_hbm_target": "not meetable as worded: HBM carries < 1 % of its peak during traversal because the "
-                                     "whole BVH stays in L2 / Infinity Cache; the kernel is limited by L1 address rate "
-                                     "(profiles/r02_trace_l1_pmc.txt, profiles/r02_ta_microbench.txt)",
+            "north_star_hbm_target": ("not meetable as worded: HBM carries a few % of its peak during traversal because the "
+                                      "whole BVH stays in L2 / Infinity Cache; the kernel is limited by L1 address rate "
+                                      "(profiles/r02_trace_l1_pmc.txt, profiles/r02_ta_microbench.txt)" if G <= 1000 else
+                                      "the one regime where HBM can matter (BVH 1.28 GB > 256 MiB Infinity Cache): see hbm_counter_frac "
+                                      "and profiles/r03_trace_pmc_10m.txt"),
             "inflight_mean_launch_ms": round(kern_ms, 4),
             "inflight_mean_launch_ms_is": f"mean start-to-end time of the timed region's launches, {S} of which overlap",
         }
@@ -560,6 +598,33 @@ def main():
     sys.exit(rc)
 
 
+def build_record(n, build_ms, sort_us, tree, G):
+    """The `build` object of the line: the build half of the metric against ITS roofline (HBM, 512 B/triangle),
+    the radix sort against its own 80 B/key formula (timed live in this run through the stage entry points), and the
+    per-kernel times of the same build from the committed rocprofv3 --kernel-trace --stats summary (profiles/)."""
+    rec = {"bound": "hbm", "ms": round(build_ms, 4), "algorithmic_bytes": 512 * n, "bytes_per_triangle": 512,
+           "achieved": round(512.0 * n / (build_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(512.0 * n / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "ms_is": "median of --build-reps builds, HIP events around all launches of rt_run_bottom_up_build / rt_run_sah_build, "
+                    "scratch preallocated, triangles resident"}
+    if sort_us:
+        rec["sort"] = {"us": round(sort_us, 1), "keys": n, "key_bits": 30, "bytes_per_key": 80,
+                       "achieved": round(80.0 * n / (sort_us * 1e-6) / 1e9, 1), "unit": "GB/s",
+                       "frac": round(80.0 * n / (sort_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                       "us_is": "median of 10 runs of rt_radix_sort_u32_pairs_bits(30) on this scene's Morton codes, events around the sort alone",
+                       "yardstick": "rocprim::radix_sort_pairs on the same keys: profiles/r03_sort_yardstick.txt (tools/sort_yardstick.hip)"}
+    stats = os.path.join(ROOT, "profiles", {708: "r03_build_1m_kernel_stats.txt", 2237: "r03_build_10m_kernel_stats.txt"}.get(G, ""))
+    if tree == "bottom-up" and os.path.isfile(stats):
+        kern = {}
+        for line in open(stats):
+            t = line.split()
+            if "calls" in t and "avg" in t:
+                kern[" ".join(t[:t.index("calls")])] = float(t[t.index("avg") + 1])
+        rec["kernels_avg_us"] = kern
+        rec["kernels_source"] = f"profiles/{os.path.basename(stats)} (rocprofv3 --kernel-trace --stats of tools/build_loop.py on this scene)"
+    return rec
+
+
 def cpu_baseline(tris, cam, W, H, spp, render_type, G, tree, gpu_frame, gpu_counts):
     """The oracle (C port of the reference algorithm, OpenMP) timed on this box's host cores on a bounded sample of the
     same workload (one full frame at 1 spp; a band of rows sized for ~20 s otherwise).  Reported baseline only.  The
@@ -578,16 +643,22 @@ def cpu_baseline(tris, cam, W, H, spp, render_type, G, tree, gpu_frame, gpu_coun
             cores = max(1, min(cores, -(-int(quota) // int(period))))
     except Exception:
         pass
+    def build_tree():
+        if tree == "bottom-up":
+            return ora.build_bvh(tris)
+        if tree == "bottom-up-pairs":
+            return ora.build_pairs(tris)
+        if tree == "hybrid":
+            return ora.build_hybrid(tris)
+        return ora.build_sah(tris, tree == "sah-pairs")
+    # the oracle's builders are OpenMP-parallel: timed with all `cores` threads and with one
+    ora.set_threads(1)
+    t0 = time.perf_counter()
+    o = build_tree()
+    t_build_one = time.perf_counter() - t0
     ora.set_threads(cores)
     t0 = time.perf_counter()
-    if tree == "bottom-up":
-        o = ora.build_bvh(tris)
-    elif tree == "bottom-up-pairs":
-        o = ora.build_pairs(tris)
-    elif tree == "hybrid":
-        o = ora.build_hybrid(tris)
-    else:
-        o = ora.build_sah(tris, tree == "sah-pairs")
+    o = build_tree()
     t_build = time.perf_counter() - t0
     root, count = o.get("root", 0), o.get("count", 2)
     # bounded sample: the whole frame when it is ~2 M rays; otherwise rows from the middle of the frame worth ~2 M rays
@@ -612,8 +683,10 @@ def cpu_baseline(tris, cam, W, H, spp, render_type, G, tree, gpu_frame, gpu_coun
            "one_thread_mrays": round(W * rows1 * spp / t_one / 1e6, 3),
            "sample": (f"1 full {W}x{H} frame" if full else f"rows [{r0}, {r1}) of the {W}x{H} frame") +
                      f" ({spp} spp) of the same scene and camera, oracle/liboracle.so (-O2 -ffp-contract=off, OpenMP over "
-                     f"rows); {names.get(tree, 'SAH')} build (single thread) of the same {tris.shape[0]} triangles",
-           "build_ms": round(t_build * 1e3, 1), "trace_s": round(t_trace, 3),
+                     f"rows); {names.get(tree, 'SAH')} build of the same {tris.shape[0]} triangles with {cores} OpenMP threads "
+                     f"(build_ms) and with one (build_ms_one_thread)",
+           "build_ms": round(t_build * 1e3, 1), "build_threads": cores, "build_ms_one_thread": round(t_build_one * 1e3, 1),
+           "trace_s": round(t_trace, 3),
            "parity": {"gpu_frame_rows_equal_oracle": frame_equal, "rows": [r0, r1],
                       "sum_box_tri_tests_equal_oracle": counts_equal,
                       "tolerance": "byte-exact (every render type: the transcendental calls of the shaded modes are csrc/rt_math.h on both sides)"}}

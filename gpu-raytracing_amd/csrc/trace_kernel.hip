@@ -189,6 +189,34 @@ __device__ __forceinline__ void slab(const uint4& a, const uint4& b, const Ray& 
     back = fminf(fminf(fmaxf(t1.x, t2.x), fmaxf(t1.y, t2.y)), fmaxf(t1z, t2z));
 }
 
+// One box step of a lane (Tracer.cu:323-352 for one pair): both slots of the current pair are loaded and both slabs
+// computed before the ordered tmax compares; a leaf in the first slot parks the lane with the second slot's slab kept.
+__device__ __forceinline__ void box_step(const TraceParams& p, const Ray& r, Trav& t)
+{
+    const uint32_t cnt = t.cur >> 29;
+    const uint4* np = reinterpret_cast<const uint4*>(p.nodes + (t.cur & kIndexMask));
+    const bool two = cnt > 1;
+    const int o1 = two ? 2 : 0;  // all four loads issue together; a lone slot is simply read twice
+    const uint4 a0 = np[0], b0 = np[1], a1 = np[o1], b1 = np[o1 + 1];
+    float f0, k0;
+    slab(a0, b0, r, f0, k0);
+    slab(a1, b1, r, t.f1, t.k1);
+    t.e1 = (b1.w & kIndexMask) | (a1.w & ~kIndexMask);
+    t.t1 = two ? (b1.w >> 29) : (uint32_t)RT_CHILD_NONE;
+    const uint32_t type0 = b0.w >> 29;
+    const uint32_t e0 = (b0.w & kIndexMask) | (a0.w & ~kIndexMask);
+    const bool valid0 = type0 != RT_CHILD_NONE;
+    const bool hit0 = valid0 & (k0 >= f0) & (f0 <= r.tmax) & (k0 >= r.tmin);
+    t.box_tests += valid0 ? 1u : 0u;
+    const bool leaf0 = hit0 & (type0 == RT_CHILD_TRI);
+    t.inner_hit(hit0 & !leaf0, e0, f0);
+    if (leaf0) { t.leaf = e0; t.phase = PH_LEAF0; }
+    else {
+        t.second_slot(r.tmin, r.tmax);
+        if (t.phase == PH_STEP) t.advance();
+    }
+}
+
 // Tracer.cu:308-374, restructured as described in the file header.  Returns tri_hit.
 // steps[0] / steps[1] count the wave's box-phase / leaf-phase iterations (profiling aid).
 __device__ __forceinline__ bool trace_ray(const TraceParams& p, Ray& r, Hit& h, Trav& t, bool active, uint32_t* steps)
@@ -215,55 +243,9 @@ __device__ __forceinline__ bool trace_ray(const TraceParams& p, Ray& r, Hit& h, 
             parked = __builtin_amdgcn_ballot_w64((t.phase - 1u) < 2u);
             if (stepping == 0 || __popcll(stepping) * p.park_den < __popcll(parked) * p.park_num) break;
             nbox += 2;   // two box steps per vote (below)
-            if (t.phase == PH_STEP) {
-                const uint32_t cnt = t.cur >> 29;
-                const uint4* np = reinterpret_cast<const uint4*>(p.nodes + (t.cur & kIndexMask));
-                const bool two = cnt > 1;
-                const int o1 = two ? 2 : 0;  // all four loads issue together; a lone slot is simply read twice
-                const uint4 a0 = np[0], b0 = np[1], a1 = np[o1], b1 = np[o1 + 1];
-                float f0, k0;
-                slab(a0, b0, r, f0, k0);
-                slab(a1, b1, r, t.f1, t.k1);
-                t.e1 = (b1.w & kIndexMask) | (a1.w & ~kIndexMask);
-                t.t1 = two ? (b1.w >> 29) : (uint32_t)RT_CHILD_NONE;
-                const uint32_t type0 = b0.w >> 29;
-                const uint32_t e0 = (b0.w & kIndexMask) | (a0.w & ~kIndexMask);
-                const bool valid0 = type0 != RT_CHILD_NONE;
-                const bool hit0 = valid0 & (k0 >= f0) & (f0 <= r.tmax) & (k0 >= r.tmin);
-                t.box_tests += valid0 ? 1u : 0u;
-                const bool leaf0 = hit0 & (type0 == RT_CHILD_TRI);
-                t.inner_hit(hit0 & !leaf0, e0, f0);
-                if (leaf0) { t.leaf = e0; t.phase = PH_LEAF0; }
-                else {
-                    t.second_slot(r.tmin, r.tmax);
-                    if (t.phase == PH_STEP) t.advance();
-                }
-            }
+            if (t.phase == PH_STEP) box_step(p, r, t);
             // second step under the same vote: halves the per-step loop overhead (ballots, branch, copies)
-            if (t.phase == PH_STEP) {
-                const uint32_t cnt = t.cur >> 29;
-                const uint4* np = reinterpret_cast<const uint4*>(p.nodes + (t.cur & kIndexMask));
-                const bool two = cnt > 1;
-                const int o1 = two ? 2 : 0;  // all four loads issue together; a lone slot is simply read twice
-                const uint4 a0 = np[0], b0 = np[1], a1 = np[o1], b1 = np[o1 + 1];
-                float f0, k0;
-                slab(a0, b0, r, f0, k0);
-                slab(a1, b1, r, t.f1, t.k1);
-                t.e1 = (b1.w & kIndexMask) | (a1.w & ~kIndexMask);
-                t.t1 = two ? (b1.w >> 29) : (uint32_t)RT_CHILD_NONE;
-                const uint32_t type0 = b0.w >> 29;
-                const uint32_t e0 = (b0.w & kIndexMask) | (a0.w & ~kIndexMask);
-                const bool valid0 = type0 != RT_CHILD_NONE;
-                const bool hit0 = valid0 & (k0 >= f0) & (f0 <= r.tmax) & (k0 >= r.tmin);
-                t.box_tests += valid0 ? 1u : 0u;
-                const bool leaf0 = hit0 & (type0 == RT_CHILD_TRI);
-                t.inner_hit(hit0 & !leaf0, e0, f0);
-                if (leaf0) { t.leaf = e0; t.phase = PH_LEAF0; }
-                else {
-                    t.second_slot(r.tmin, r.tmax);
-                    if (t.phase == PH_STEP) t.advance();
-                }
-            }
+            if (t.phase == PH_STEP) box_step(p, r, t);
         }
         if ((stepping | parked) == 0) break;
         // ---------------------------------------------------- leaf phase (Tracer.cu:333-337, 293-306)
@@ -291,8 +273,10 @@ __device__ __forceinline__ bool trace_ray(const TraceParams& p, Ray& r, Hit& h, 
             if (t.phase == PH_STEP) t.advance();
         }
     }
+#ifndef RT_TRACE_NO_STEPS
     steps[0] += nbox;
     steps[1] += nleaf;
+#endif
     return tri_hit;
 }
 
@@ -619,7 +603,12 @@ __device__ __forceinline__ void shade_sample(const TraceParams& p, const rt_came
 template <int RENDER>
 // kDepth / kBoxtests / kTriangleTests end in a one-line colour conversion: they fit 64 VGPRs (8 waves per SIMD); the
 // shading of the other render types would spill there, they keep 72 VGPRs (7 waves)
-__global__ __launch_bounds__(kTraceWaves * 64, (RENDER <= 2 || RENDER == kRenderDebugBoxCount) ? RT_TRACE_MIN_WAVES + 1 : RT_TRACE_MIN_WAVES)
+// (RT_TRACE_LEAN_EXTRA = 0 and RT_TRACE_NO_STEPS are the compile-time arms of tools/trace_spill_experiment.sh, which priced
+// the spills of the 64-VGPR instantiations: see DESIGN section 5)
+#ifndef RT_TRACE_LEAN_EXTRA
+#define RT_TRACE_LEAN_EXTRA 1
+#endif
+__global__ __launch_bounds__(kTraceWaves * 64, (RENDER <= 2 || RENDER == kRenderDebugBoxCount) ? RT_TRACE_MIN_WAVES + RT_TRACE_LEAN_EXTRA : RT_TRACE_MIN_WAVES)
 void trace_kernel(TraceParams p)
 {
     __shared__ uint32_t stack_lds[kTraceWaves][kStackLds][64];
