@@ -1397,6 +1397,11 @@ hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, boo
             sah_partition_kernel<<<chunks, 256, 0, st>>>(a, lvl);
         }
         sah_small_kernel<<<kSmallGrid, kSmallWaves * 64, 0, st>>>(a, small_done);
+        // The patch copies every cell's sub-root descriptor (w12 / w28 of the cell tree's root slot) into its top-tree leaf,
+        // guarded by "not patched yet" (count bits == 0), so the copy made after the FIRST batch is final.  Invariant: a
+        // cell's root is a level-0 task (or a small task queued by sah_roots_kernel), and the first batch runs at least
+        // three levels plus the small-task kernel, so every cell root has written its descriptor before this launch; later
+        // batches only finish tasks deeper in the trees and find nothing left to patch.
         sah_patch_top_kernel<<<1, 128, 0, st>>>(a, splits ? 1 : 0);
         uint32_t live = 0, hdr[9] = {0};   // status[0..7] and small_count are adjacent in SahHeader
         static_assert(offsetof(SahHeader, small_count) == offsetof(SahHeader, status) + 32, "one copy reads both");
@@ -1406,6 +1411,7 @@ hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, boo
         if (e != hipSuccess) return e;
         small_done = hdr[8];
         if (status0) *status0 = hdr[0];
+        if (levels_run) *levels_run = lvl;           // (also on the error returns below)
         if (hdr[0] != 0) return hipSuccess;          // a kernel flagged an incomplete build (kSahErrLocals): stop here
         if (live == 0) break;
         if (lvl + 1 >= kSahMaxLevels) {

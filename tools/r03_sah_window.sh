@@ -1,0 +1,10 @@
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT/gpu-raytracing_amd/csrc
+cp librt_amd.so /tmp/librt_amd.orig.so
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I../../include -I."
+for W in 1 2 3 4 8; do
+  /opt/rocm/bin/hipcc $F -DRT_SAH_SMALL_WINDOW=$W -c sah_build.hip -o /tmp/sah_w$W.o || exit 1
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o librt_amd.so build_front.o radix_sort.o lbvh_levels.o hybrid_top.o /tmp/sah_w$W.o rt_abi.o trace_kernel.o || exit 1
+  (cd $GRAFT_REPO_ROOT && rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r3k/w$W -- python3 tools/sah_loop.py > /dev/null 2>&1; echo "window $W: $(python3 tools/kstats.py gpurun_out/r3k/w$W | grep small)")
+done
+cp /tmp/librt_amd.orig.so librt_amd.so
