@@ -471,256 +471,6 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
     RT_STAMP(LEAF ? 0 : 1, so + 4);
 }
 
-// ---- the leaf level, wave-synchronous (round 3).
-//
-// level_pass<true> lets every leaf's thread climb on its own: siblings rendezvous through an LDS exchange and the second
-// arriver carries on.  Its waves run the merge step as often as their longest chain needs it (12 - 13 times) with a quarter
-// of their lanes live on average (SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU) = 0.25, profiles/r03_build_pmc_1m.txt), and
-// the kernel is bound by the instructions it issues (21.7 M wave-instructions x ~4.4 cycles / 1024 SIMDs = 39 of its 57 us
-// at 1M triangles).  Here the same merges are scheduled by ROUNDS inside a wave instead: every live segment picks the
-// side of its larger end delta; a segment that goes right and the next live segment above it that goes left are siblings
-// (adjacent live segments always share a boundary), found with three ballots; the left one pulls its sibling's state
-// across with wave shuffles, emits the parent's node pair into the staging area and lives on as the parent; the right one
-// dies.  No LDS exchange, no lock, no atomics, no first / second arriver: a round is ~100 instructions for the whole wave
-// and a wave needs as many rounds as the forest over its 64 leaves is high (6 - 9).  What stays open at a wave's edges is
-// compacted, in leaf order, into the state arrays and taken up by the next PASS: thread j continues with segment j, so
-// after the first pass (8 waves x 64 leaves) the ~50 survivors sit in ONE wave, whose rounds finish the block.  A pass
-// that held all its segments in one wave is a fixpoint (every adjacent pair was inside it).  Otherwise passes repeat with
-// the chunk boundaries shifted by 32 segments every other pass; two passes in a row without a merge mean every pair has
-// been inside a chunk and refused: done.  (Deep trees -- long runs of equal codes -- can leave more than 64 open roots in
-// a block: that is the multi-pass case; the open-root bound of 2 x depth = 124 <= kMaxOpen is unchanged.)
-// Same nodes as the climb: the radix tree is unique, and index, slot and parent words of a node depend on its range and
-// its end deltas only.
-__device__ __forceinline__ void leaf_pass(const LevelArgs& a, uint32_t* smem, uint32_t n, uint32_t B0, uint32_t S,
-                                          uint32_t* out_cnt, uint32_t* out_rec)
-{
-    using C = LeafCfg;
-    static_assert(C::CAP == C::NT, "one leaf per thread");
-    static_assert(C::CAP <= 2048, "two 16-bit leaf indices per state word");
-    constexpr uint32_t NW = C::NT / 64;
-    RT_STAMP(0, 0);
-    int* dl = reinterpret_cast<int*>(smem + C::oDl);
-    uint32_t* s_misc = smem + C::oLock;        // (the exchange locks of the climb are not used here)
-    uint32_t* s_range = smem + C::oRange;
-    uint32_t* s_desc = smem + C::oDesc;
-    float* s_box = reinterpret_cast<float*>(smem + C::oBox);
-    uint32_t* ws = smem + C::oWs;
-    uint32_t* stage = smem + C::oStage;
-    uint32_t* sink = smem + C::oSink;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-
-    // dword 7 (w28 of slot 0: child | type, never 0 for a real slot) doubles as the "pair was completed here" marker
-    stage[tid * 16 + 7] = 0u;
-    for (uint32_t b = tid; b <= S; b += C::NT) dl[b] = S ? delta_adjacent(a.codes, (int)B0 + (int)b - 1, n) : -1;
-    __syncthreads();
-    RT_STAMP(0, 1);
-
-    // ---- this thread's leaf (GenerateTriangles + the leaf box of GenerateAABBs, BottomUpBuilder.cu:287-312, :259-267)
-    bool live = tid < S;
-    uint32_t sf = tid, sl = tid, desc = 0, cc = 0;
-    int ldl = -1, rdl = -1;
-    float bx[6] = {0, 0, 0, 0, 0, 0};
-    if (live) {
-        const uint32_t i = B0 + tid;
-        uint32_t sv = a.sorted_idx[i];
-        uint32_t src = sv & 0x7FFFFFFFu;
-        // the gather address comes from memory: never past the triangle array (a quad leaf also reads triangle src + 1)
-        if (src + (sv >> 31) >= a.n) {
-            atomicOr(a.status, kErrSortedIndex);
-            sv = src = 0u;
-        }
-        float v[9];
-        load_tri9(a.tris + (size_t)src * 9, v);   // 36 bytes at a 4-byte-aligned address: 2 x 16-byte loads + 1 dword
-        uint4* out = reinterpret_cast<uint4*>(a.leaves + i);
-        float v3[3] = {v[6], v[7], v[8]};
-        if (sv >> 31) {
-            // a quad leaf (--pairs): CreateTrianglePair (Pairing.cuh:60-77): A rotated so the shared edge is
-            // (v1, v2), v3 = B's vertex off that edge; ids = (src, src+1); rotations = (rot_a, rot_b)
-            float B[9];
-            load_tri9(a.tris + (size_t)src * 9 + 9, B);
-            int ra = 0, rb = 0;
-            can_form_pair(v, B, ra, rb);
-            float r[9];
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                r[k] = ra == 1 ? v[6 + k] : (ra == 2 ? v[3 + k] : v[k]);
-                r[3 + k] = ra == 1 ? v[k] : (ra == 2 ? v[6 + k] : v[3 + k]);
-                r[6 + k] = ra == 1 ? v[3 + k] : (ra == 2 ? v[k] : v[6 + k]);
-                v3[k] = rb == 2 ? B[k] : (rb == 1 ? B[3 + k] : B[6 + k]);
-            }
-#pragma unroll
-            for (int k = 0; k < 9; k++) v[k] = r[k];
-            out[0] = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), src);
-            out[1] = make_uint4(__float_as_uint(v[3]), __float_as_uint(v[4]), __float_as_uint(v[5]), src + 1);
-            out[2] = make_uint4(__float_as_uint(v[6]), __float_as_uint(v[7]), __float_as_uint(v[8]), (uint32_t)ra | ((uint32_t)rb << 16));
-            out[3] = make_uint4(__float_as_uint(v3[0]), __float_as_uint(v3[1]), __float_as_uint(v3[2]), 0u);
-        } else {
-            // ids defined: primitive_id_0 = the original triangle, the rest 0; v3 = v2
-            out[0] = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), src);
-            out[1] = make_uint4(__float_as_uint(v[3]), __float_as_uint(v[4]), __float_as_uint(v[5]), 0u);
-            out[2] = make_uint4(__float_as_uint(v[6]), __float_as_uint(v[7]), __float_as_uint(v[8]), 0u);
-            out[3] = make_uint4(__float_as_uint(v[6]), __float_as_uint(v[7]), __float_as_uint(v[8]), 0u);
-        }
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            bx[k] = fminf(fminf(fminf(v[k], v[3 + k]), v[6 + k]), v3[k]);
-            bx[3 + k] = fmaxf(fmaxf(fmaxf(v[k], v[3 + k]), v[6 + k]), v3[k]);
-        }
-        desc = (i & kIndexMask) | ((uint32_t)RT_CHILD_TRI << 29);
-        ldl = dl[tid];
-        rdl = dl[tid + 1];
-    }
-    RT_STAMP(0, 2);
-
-    const uint64_t bit = 1ull << lane, below_mask = bit - 1ull, above_mask = ~(below_mask | bit);
-    uint32_t cnt = S, off = 0, zero_passes = 0;
-    while (true) {
-        // ---- rounds of this wave's chunk
-        bool merged_any = false;
-        while (true) {
-            const bool fin = live && ((ldl & rdl) < 0);        // covers every leaf of the scene: the finished root
-            const bool goR = live && !fin && ldl < rdl;        // I am the LEFT child of my parent: my sibling is above me
-            const bool goL = live && !fin && !goR;
-            const uint64_t Lm = __builtin_amdgcn_ballot_w64(live), Rm = __builtin_amdgcn_ballot_w64(goR),
-                           Gm = __builtin_amdgcn_ballot_w64(goL);
-            const uint64_t up = Lm & above_mask, dn = Lm & below_mask;
-            const uint32_t nb = up ? (uint32_t)__builtin_ctzll(up) : 0u;
-            const bool mergeA = goR && up != 0 && ((Gm >> nb) & 1ull);                       // I absorb the segment on lane nb
-            const bool dies = goL && dn != 0 && ((Rm >> (63u - (uint32_t)__builtin_clzll(dn))) & 1ull);   // ... and it is absorbed
-            if (__builtin_amdgcn_ballot_w64(mergeA) == 0) break;
-            merged_any = true;
-            // my sibling's state (every lane takes part in the shuffles; only mergeA lanes use what they get)
-            const int srcl = (int)(mergeA ? nb : lane);
-            float ob[6];
-#pragma unroll
-            for (int k = 0; k < 6; k++) ob[k] = __shfl(bx[k], srcl, 64);
-            const uint32_t odesc = (uint32_t)__shfl((int)desc, srcl, 64), occ = (uint32_t)__shfl((int)cc, srcl, 64);
-            const uint32_t osl = (uint32_t)__shfl((int)sl, srcl, 64);
-            const int ordl = __shfl(rdl, srcl, 64);
-            if (mergeA) {
-                // the parent: range [sf, osl], end deltas (ldl, ordl); a LEFT child of ITS parent iff ldl < ordl, and then
-                // numbered by its last leaf, else by its first (Karras: BottomUpBuilder.cu:188-194); the root is node 0
-                const bool is_root = (ldl & ordl) < 0;
-                const uint32_t idx = is_root ? 0u : (ldl < ordl ? B0 + osl : B0 + sf);
-                const bool mbox = (desc >> 29) == RT_CHILD_BOX, obox = (odesc >> 29) == RT_CHILD_BOX;
-                // its pair = [left child: box, descriptor][right child: box, descriptor], into the staging area (every node a
-                // block completes has its index in the block's own leaf range)
-                uint32_t* nw = stage + (idx - B0) * 16;
-                nw[0] = __float_as_uint(bx[0]); nw[1] = __float_as_uint(bx[1]); nw[2] = __float_as_uint(bx[2]);
-                *reinterpret_cast<uint4*>(nw + 4) = make_uint4(__float_as_uint(bx[3]), __float_as_uint(bx[4]), __float_as_uint(bx[5]), desc);
-                nw[8] = __float_as_uint(ob[0]); nw[9] = __float_as_uint(ob[1]); nw[10] = __float_as_uint(ob[2]);
-                *reinterpret_cast<uint4*>(nw + 12) = make_uint4(__float_as_uint(ob[3]), __float_as_uint(ob[4]), __float_as_uint(ob[5]), odesc);
-                // parent:29 | count:3 of the children's own pairs (BottomUpBuilder.cu:204-213, :265, :282); a leaf child has
-                // no pair: its two words go to a sink
-                {
-                    uint32_t* c = mbox ? stage + ((desc & kIndexMask) / 2 - B0) * 16 : sink;
-                    c[3] = (idx * 2) | (((cc & 1u) ? 2u : 1u) << 29);
-                    c[11] = (idx * 2) | (((cc & 2u) ? 2u : 1u) << 29);
-                }
-                {
-                    uint32_t* c = obox ? stage + ((odesc & kIndexMask) / 2 - B0) * 16 : sink;
-                    c[3] = (idx * 2 + 1) | (((occ & 1u) ? 2u : 1u) << 29);
-                    c[11] = (idx * 2 + 1) | (((occ & 2u) ? 2u : 1u) << 29);
-                }
-                sl = osl;
-                rdl = ordl;
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    bx[k] = fminf(bx[k], ob[k]);
-                    bx[3 + k] = fmaxf(bx[3 + k], ob[3 + k]);
-                }
-                desc = ((idx * 2) & kIndexMask) | ((uint32_t)RT_CHILD_BOX << 29);
-                cc = (mbox ? 1u : 0u) | (obox ? 2u : 0u);
-            }
-            if (dies) live = false;
-        }
-        // ---- what is still live, compacted in leaf order into the state arrays
-        const uint64_t Lm = __builtin_amdgcn_ballot_w64(live);
-        if (lane == 0) { ws[wave] = (uint32_t)__popcll(Lm); ws[NW + wave] = merged_any ? 1u : 0u; }
-        __syncthreads();
-        uint32_t base = 0, total = 0, any = 0;
-#pragma unroll
-        for (uint32_t w = 0; w < NW; w++) {
-            const uint32_t c = ws[w];
-            base += w < wave ? c : 0u;
-            total += c;
-            any |= ws[NW + w];
-        }
-        if (live) {
-            const uint32_t pos = base + (uint32_t)__popcll(Lm & below_mask);
-            s_range[pos] = sf | (sl << 16);
-            s_misc[pos] = (uint32_t)(ldl + 1) | ((uint32_t)(rdl + 1) << 8) | (cc << 16);
-            s_desc[pos] = desc;
-#pragma unroll
-            for (int k = 0; k < 6; k++) s_box[k * C::CAP + pos] = bx[k];
-        }
-        __syncthreads();   // (also: the staging writes of this pass are complete)
-        const bool fixpoint = cnt + off <= 64;       // the pass held all its segments in one wave
-        cnt = total;
-        if (fixpoint) break;
-        zero_passes = any ? 0u : zero_passes + 1u;
-        if (zero_passes >= 2) break;
-        off = (off == 0 && cnt > 64 && cnt + 32 <= C::NT) ? 32u : 0u;   // (no room to shift: the compaction itself has moved the boundaries)
-        // ---- the next pass: thread off + j continues with segment j
-        const uint32_t j = tid - off;
-        live = tid >= off && j < cnt;
-        if (live) {
-            const uint32_t rg = s_range[j], ms = s_misc[j];
-            sf = rg & 0xFFFFu; sl = rg >> 16;
-            ldl = (int)(ms & 0xFFu) - 1; rdl = (int)((ms >> 8) & 0xFFu) - 1; cc = ms >> 16;
-            desc = s_desc[j];
-#pragma unroll
-            for (int k = 0; k < 6; k++) bx[k] = s_box[k * C::CAP + j];
-        }
-        // (the next compaction writes the arrays behind its first barrier: every thread has read its segment by then)
-    }
-    RT_STAMP(0, 3);
-
-    // ---- what is left: the block's open roots, in leaf order -- or the finished root of the whole tree
-    uint32_t nrec = cnt;
-    if (tid < cnt) {
-        const uint32_t rg = s_range[tid], ms = s_misc[tid];
-        const int l0 = (int)(ms & 0xFFu) - 1, r0 = (int)((ms >> 8) & 0xFFu) - 1;
-        const uint32_t d0 = s_desc[tid], c0 = ms >> 16;
-        if ((l0 & r0) < 0) {
-            // the finished root of the whole tree (the only survivor): not an open root.  Q3: the reference leaves the root
-            // pair's parent undefined; defined as 0
-            if ((d0 >> 29) == RT_CHILD_BOX) {
-                stage[3] = ((c0 & 1u) ? 2u : 1u) << 29;
-                stage[11] = ((c0 & 2u) ? 2u : 1u) << 29;
-            }
-        } else if (tid < kMaxOpen) {
-            uint4* o = reinterpret_cast<uint4*>(out_rec + (size_t)tid * kRecDwords);
-            store_sc1(o + 0, B0 + (rg & 0xFFFFu), B0 + (rg >> 16), d0, c0);
-            store_sc1(o + 1, __float_as_uint(s_box[0 * C::CAP + tid]), __float_as_uint(s_box[1 * C::CAP + tid]),
-                      __float_as_uint(s_box[2 * C::CAP + tid]), __float_as_uint(s_box[3 * C::CAP + tid]));
-            store_sc1(o + 2, __float_as_uint(s_box[4 * C::CAP + tid]), __float_as_uint(s_box[5 * C::CAP + tid]), (uint32_t)l0, (uint32_t)r0);
-        }
-    }
-    if (tid == 0) {
-        if (cnt == 1) {
-            const uint32_t ms = s_misc[0];
-            if ((((int)(ms & 0xFFu) - 1) & ((int)((ms >> 8) & 0xFFu) - 1)) < 0) nrec = 0;   // the finished root
-        }
-        store_sc1(out_cnt, min(nrec, kMaxOpen));
-        if (nrec > kMaxOpen) atomicOr(a.status, kErrOpenOverflow);  // cannot happen: <= 2 * depth(62) open roots
-    }
-    __syncthreads();   // (the root's parent words are staged)
-    {
-        // the completed pairs of this block, 16 bytes per lane, consecutive lanes on consecutive addresses.  A pair whose
-        // parent is completed at an upper level leaves with undefined w12 words (dwords 3 and 11); the upper-level
-        // kernel, which runs after this one, writes them -- as it writes every word of the pairs not completed here.
-        const uint4* st4 = reinterpret_cast<const uint4*>(stage);
-        uint4* dst = reinterpret_cast<uint4*>(a.nodes + (size_t)B0 * 2);
-#pragma unroll
-        for (uint32_t k = 0; k < 4 * C::CAP / C::NT; k++) {
-            const uint32_t c = tid + k * C::NT;          // 16-byte chunk; pair = c / 4
-            if ((stage[(c >> 2) * 16 + 7] >> 29) != 0u) dst[c] = st4[c];
-        }
-    }
-    RT_STAMP(0, 4);
-}
-
 // prefix table of the open-root counts of `nb` (<= 64) source blocks -> pref[0..64] in LDS; returns their sum
 __device__ __forceinline__ uint32_t load_prefix(uint32_t* smem, const uint32_t* src_cnt, uint32_t nb)
 {
@@ -1024,11 +774,7 @@ __global__ __launch_bounds__(kLeafThreads, 6) void lbvh_leaf_kernel(LevelArgs a)
     const uint32_t blk = blockIdx.x;
     const uint32_t B0 = blk * kLeafCap;
     const uint32_t S = B0 < n ? min(kLeafCap, n - B0) : 0u;
-#ifdef RT_LBVH_LEAF_CLIMB
     level_pass<true>(a, smem, n, B0, S, nullptr, a.cnt[0] + blk, a.rec[0] + (size_t)blk * kMaxOpen * kRecDwords);
-#else
-    leaf_pass(a, smem, n, B0, S, a.cnt[0] + blk, a.rec[0] + (size_t)blk * kMaxOpen * kRecDwords);
-#endif
 }
 
 // ---- all upper levels in one launch: one workgroup per level-1 block; the workgroup that completes the inputs of a
