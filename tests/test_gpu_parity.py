@@ -92,6 +92,27 @@ def test_radix_sort_stable(rt, ora, n, bits):
     assert (sk == keys[order]).all() and (sv == vals[order]).all()
 
 
+@pytest.mark.parametrize("n", [1, 4097, 300001, 2097152 + 7])
+@pytest.mark.parametrize("key_bits", [30, 17, 32])
+@pytest.mark.parametrize("in_tmp", [False, True])
+def test_radix_sort_bits_entry_point(rt, n, key_bits, in_tmp):
+    """rt_radix_sort_u32_pairs_bits: keys of `key_bits` significant bits, input on either side (the library copies it across
+    only when the pass count wants it elsewhere); result in keys / values, equal to a stable sort."""
+    import torch
+    rng = np.random.default_rng(n + key_bits)
+    keys = rng.integers(0, 2 ** key_bits, size=n, dtype=np.uint64).astype(np.uint32)
+    keys[::3] = keys[0]                                  # heavy duplicates: stability matters
+    vals = np.arange(n, dtype=np.uint32)
+    dk, dv = rt.to_device(keys).view(torch.int32), rt.to_device(vals).view(torch.int32)
+    junk = torch.full_like(dk, -1)
+    k, v, tk, tv = (junk.clone(), junk.clone(), dk.clone(), dv.clone()) if in_tmp else (dk.clone(), dv.clone(), junk.clone(), junk.clone())
+    assert rt.lib().rt_radix_sort_input_in_tmp(n, key_bits) in (0, 1)
+    rt.RadixSortBits(k, v, tk, tv, n, key_bits, input_in_tmp=in_tmp)
+    order = np.argsort(keys, kind="stable")
+    assert (k.cpu().numpy().view(np.uint32) == keys[order]).all()
+    assert (v.cpu().numpy().view(np.uint32) == vals[order]).all()
+
+
 @pytest.mark.parametrize("n", [0, 1, 2, 3, 5])
 def test_tiny_builds(rt, scenes, ora, n):
     """n < 2 is special-cased; 2..5 exercise a single tiny workgroup."""
