@@ -113,6 +113,41 @@ def test_radix_sort_bits_entry_point(rt, n, key_bits, in_tmp):
     assert (v.cpu().numpy().view(np.uint32) == vals[order]).all()
 
 
+@pytest.mark.parametrize("pattern", ["equal", "sorted", "reversed", "two", "blocks", "misaligned"])
+def test_radix_sort_adversarial_inputs(rt, pattern):
+    """Key distributions that stress the histogram kernels' clustered-digit path (lanes queueing on one LDS word), the
+    ballot ranking with 64 equal digits, and the scalar (not 16-byte aligned) key path: all equal, already sorted, reversed,
+    two values alternating, long constant runs, and key / value pointers offset by one element."""
+    import torch
+    n = 1_000_003
+    rng = np.random.default_rng(7)
+    if pattern == "equal":
+        keys = np.full(n, 0xDEADBEEF, np.uint32)
+    elif pattern == "sorted":
+        keys = np.sort(rng.integers(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32))
+    elif pattern == "reversed":
+        keys = np.sort(rng.integers(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32))[::-1].copy()
+    elif pattern == "two":
+        keys = np.where(np.arange(n) % 2 == 0, 0x01010101, 0xFEFEFEFE).astype(np.uint32)
+    elif pattern == "blocks":
+        keys = np.repeat(rng.integers(0, 2 ** 32, size=n // 5000 + 1, dtype=np.uint64).astype(np.uint32), 5000)[:n]
+    else:
+        keys = rng.integers(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32)
+    vals = np.arange(n, dtype=np.uint32)
+    shift = 1 if pattern == "misaligned" else 0          # element offset into over-allocated buffers: 4-byte alignment only
+    bufs = [torch.zeros(n + 4, dtype=torch.int32, device="cuda") for _ in range(4)]
+    dk, dv, t1, t2 = (b[shift:shift + n] for b in bufs)
+    dk.copy_(rt.to_device(keys).view(torch.int32))
+    dv.copy_(rt.to_device(vals).view(torch.int32))
+    rt.RadixSort(dk, dv, t1, t2, n)
+    order = np.argsort(keys, kind="stable")
+    assert (dk.cpu().numpy().view(np.uint32) == keys[order]).all()
+    assert (dv.cpu().numpy().view(np.uint32) == vals[order]).all()
+    # nothing outside the n elements was touched (the scatter goes through range-checked buffer descriptors)
+    for b in bufs:
+        assert int(b[:shift].abs().sum()) == 0 and int(b[shift + n:].abs().sum()) == 0
+
+
 @pytest.mark.parametrize("n", [0, 1, 2, 3, 5])
 def test_tiny_builds(rt, scenes, ora, n):
     """n < 2 is special-cased; 2..5 exercise a single tiny workgroup."""
