@@ -20,14 +20,16 @@ namespace rt {
 constexpr uint32_t kIndexMask = 0x1FFFFFFFu;  // 29-bit child / parent field (Common.cuh:152-159)
 
 // ---- DeviceUtils.cuh:3-13: monotone float <-> int so integer min/max == float min/max
+// (i >= 0) ? i : i ^ 0x7FFFFFFF, written without the select: an arithmetic shift + one v_bitop3 instead of xor + compare +
+// select -- these conversions are a visible share of the instructions of the SAH kernels and of the scene-box kernel
 __device__ __forceinline__ int float_to_ordered_int(float f)
 {
-    int i = __float_as_int(f);
-    return (i >= 0) ? i : i ^ 0x7FFFFFFF;
+    const int i = __float_as_int(f);
+    return i ^ ((i >> 31) & 0x7FFFFFFF);
 }
 __device__ __forceinline__ float ordered_int_to_float(int i)
 {
-    return __int_as_float((i >= 0) ? i : i ^ 0x7FFFFFFF);
+    return __int_as_float(i ^ ((i >> 31) & 0x7FFFFFFF));
 }
 
 // ---- wave64 helpers

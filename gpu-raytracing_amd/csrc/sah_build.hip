@@ -697,15 +697,23 @@ __global__ __launch_bounds__(256) void sah_bin_kernel(SahArgs a, uint32_t lvl)
                 val[6 + k] = float_to_ordered_int(ctr[k]);
                 val[9 + k] = ~float_to_ordered_int(ctr[k]);
             }
+            // rotate val[] left by r = lane mod 12 (val[k] <- val[(k + r) mod 12]) with a four-stage barrel shifter -- by 1, 2,
+            // 4, 8 on the bits of r: 48 selects instead of the 132 of a select chain per word
             const uint32_t r = threadIdx.x % 12u;
 #pragma unroll
-            for (int k = 0; k < 12; k++) {
-                uint32_t w = r + (uint32_t)k;
-                w = w >= 12u ? w - 12u : w;
-                int v = val[0];
+            for (int st = 0; st < 4; st++) {
+                const bool on = (r >> st) & 1u;
+                int t[12];
 #pragma unroll
-                for (int j = 1; j < 12; j++) v = w == (uint32_t)j ? val[j] : v;
-                atomicMin(&lb[w], v);
+                for (int k = 0; k < 12; k++) t[k] = val[(k + (1 << st)) % 12];
+#pragma unroll
+                for (int k = 0; k < 12; k++) val[k] = on ? t[k] : val[k];
+            }
+            uint32_t w = r;
+#pragma unroll
+            for (int k = 0; k < 12; k++) {
+                atomicMin(&lb[w], val[k]);
+                w = w == 11u ? 0u : w + 1u;
             }
             // the count: one atomic per (task, bin) group of the wave instead of one per lane
             uint64_t m = __builtin_amdgcn_ballot_w64(true);
@@ -1040,11 +1048,19 @@ __global__ __launch_bounds__(256) void sah_partition_kernel(SahArgs a, uint32_t 
 // atomics, stable partition with ballots, items moved to their new lanes with ds_permute.
 constexpr uint32_t kSmallSegs = 22;   // sub-tasks with >= 3 items alive in one level (<= 64 / 3)
 
+// Word-major LDS tables: the word index of every access is a compile-time constant, so clearing a table is a few stores of
+// immediates (the item-major layout of round 2 cleared with `(j % 6) < 3 ? lo : hi` -- an integer modulo per store, ~200 of
+// the ~970 vector instructions a level cost; the kernel is bound by instruction issue, profiles/r03_sah_small_experiments.txt)
 struct SmallSmem {
-    int sbox[2][64][12];              // [buffer][first lane of the sub-task][p box 6, c box 6], ordered ints
-    int bins[kSmallSegs][8][6];       // primitive box per bin
+    int sbox[2][12][64];              // [buffer][p box 6, c box 6][first lane of the sub-task], ordered ints
+    int bins[7][kSmallSegs * 8];      // [primitive box 6, count][sub-task * 8 + bin]
     uint32_t splane[64], snl[64], skind[64];
 };
+__device__ __forceinline__ void small_box_to_float(const int (*t)[64], uint32_t s, float* f)   // words 0..5 of column s
+{
+#pragma unroll
+    for (int k = 0; k < 6; k++) f[k] = ordered_int_to_float(t[k][s]);
+}
 
 // LDS traffic between the lanes of ONE wave: its DS operations execute in order, so only the compiler has to be kept
 // from moving memory operations across the point
@@ -1074,20 +1090,21 @@ __device__ __forceinline__ void sah_small_task(const SahArgs& a, SmallSmem& S, u
     bool active = lane < cnt;
     uint32_t cur = 0;
     // root boxes
-    for (uint32_t j = lane; j < 64 * 12; j += 64) (&S.sbox[0][0][0])[j] = (j % 6) < 3 ? kEmptyLo : kEmptyHi;
+#pragma unroll
+    for (int w = 0; w < 12; w++) S.sbox[0][w][lane] = (w % 6) < 3 ? kEmptyLo : kEmptyHi;
     wave_lds_sync();
     if (active) {
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             const int ctr = float_to_ordered_int((b[k] + b[3 + k]) * 0.5f);
-            atomicMin(&S.sbox[0][0][k], float_to_ordered_int(b[k]));
-            atomicMax(&S.sbox[0][0][3 + k], float_to_ordered_int(b[3 + k]));
-            atomicMin(&S.sbox[0][0][6 + k], ctr);
-            atomicMax(&S.sbox[0][0][9 + k], ctr);
+            atomicMin(&S.sbox[0][k][0], float_to_ordered_int(b[k]));
+            atomicMax(&S.sbox[0][3 + k][0], float_to_ordered_int(b[3 + k]));
+            atomicMin(&S.sbox[0][6 + k][0], ctr);
+            atomicMax(&S.sbox[0][9 + k][0], ctr);
         }
     }
     wave_lds_sync();
-    if ((R.flags & 4u) && lane < 6) S.sbox[0][0][6 + lane] = a.H->gc[lane];   // the top root's centroid bounds are the scene's
+    if ((R.flags & 4u) && lane < 6) S.sbox[0][6 + lane][0] = a.H->gc[lane];   // the top root's centroid bounds are the scene's
     wave_lds_sync();
 
     while (__builtin_amdgcn_ballot_w64(active)) {
@@ -1102,7 +1119,7 @@ __device__ __forceinline__ void sah_small_task(const SahArgs& a, SmallSmem& S, u
                 sah_leaf_desc(a, a.nodes + child + (lane - s), idv);
                 if (lane == s) {
                     float pb[6];
-                    ibox_to_float(&S.sbox[cur][s][0], pb);
+                    small_box_to_float(S.sbox[cur], s, pb);
                     sah_put_node(a.nodes + parent, pb, child, 2u, RT_CHILD_BOX);
                 }
             }
@@ -1114,11 +1131,15 @@ __device__ __forceinline__ void sah_small_task(const SahArgs& a, SmallSmem& S, u
         const uint32_t nseg = (uint32_t)__popcll(leaders);
         const uint32_t seg = (uint32_t)__popcll(leaders & ((1ull << s) - 1ull));
         const uint64_t segmask = active ? (((e >= 64 ? ~0ull : ((1ull << e) - 1ull))) & ~((1ull << s) - 1ull)) : 0ull;
-        for (uint32_t j = lane; j < nseg * 48; j += 64) (&S.bins[0][0][0])[j] = (j % 6) < 3 ? kEmptyLo : kEmptyHi;
-        for (uint32_t j = lane; j < 64 * 12; j += 64) (&S.sbox[nxt][0][0])[j] = (j % 6) < 3 ? kEmptyLo : kEmptyHi;
+        for (uint32_t j = lane; j < nseg * 8; j += 64) {
+#pragma unroll
+            for (int w = 0; w < 7; w++) S.bins[w][j] = w < 3 ? kEmptyLo : (w < 6 ? kEmptyHi : 0);
+        }
+#pragma unroll
+        for (int w = 0; w < 12; w++) S.sbox[nxt][w][lane] = (w % 6) < 3 ? kEmptyLo : kEmptyHi;
         float c[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) c[k] = active ? ordered_int_to_float(S.sbox[cur][s][6 + k]) : 0.0f;
+        for (int k = 0; k < 6; k++) c[k] = active ? ordered_int_to_float(S.sbox[cur][6 + k][s]) : 0.0f;
         const bool binned = active && !(sah_sa(c) <= 0.0f);
         int bin = 0;
         if (binned) {
@@ -1132,15 +1153,14 @@ __device__ __forceinline__ void sah_small_task(const SahArgs& a, SmallSmem& S, u
         }
         wave_lds_sync();
         if (binned) {
+            const uint32_t cell = seg * 8 + (uint32_t)bin;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                atomicMin(&S.bins[seg][bin][k], float_to_ordered_int(b[k]));
-                atomicMax(&S.bins[seg][bin][3 + k], float_to_ordered_int(b[3 + k]));
+                atomicMin(&S.bins[k][cell], float_to_ordered_int(b[k]));
+                atomicMax(&S.bins[3 + k][cell], float_to_ordered_int(b[3 + k]));
             }
+            atomicAdd(&S.bins[6][cell], 1);     // items per bin (round 2: eight 64-bit ballot popcounts per level)
         }
-        uint32_t bn[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) bn[q] = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(binned && bin == q) & segmask);
         wave_lds_sync();
         // ---- SelectPlane (SharedTaskBuilder.cu:297-350): the sub-task's first lane sweeps the bins left -> right, its
         // second lane right -> left -- the SAME instructions on two lanes (a sub-task here has >= 3 lanes) -- then the
@@ -1150,13 +1170,24 @@ __device__ __forceinline__ void sah_small_task(const SahArgs& a, SmallSmem& S, u
             float sa_run[7];
             uint32_t n_run[7];
             if (fwd || bwd) {
+                // the seven bins of this sweep first -- 49 LDS reads in flight at once instead of a read-wait-merge chain --
+                // then the running union, its surface area and the running count, in registers
+                int bw[7][6];
+                uint32_t bc[7];
+#pragma unroll
+                for (int i = 0; i < 7; i++) {
+                    const uint32_t cell = seg * 8 + (uint32_t)(bwd ? 7 - i : i);
+#pragma unroll
+                    for (int k = 0; k < 6; k++) bw[i][k] = S.bins[k][cell];
+                    bc[i] = (uint32_t)S.bins[6][cell];
+                }
                 int run[6] = {kEmptyLo, kEmptyLo, kEmptyLo, kEmptyHi, kEmptyHi, kEmptyHi};
                 uint32_t cc = 0;
 #pragma unroll
                 for (int i = 0; i < 7; i++) {
-                    const int bi = bwd ? 7 - i : i;
-                    ibox_merge(run, &S.bins[seg][bi][0]);
-                    cc += bwd ? bn[7 - i] : bn[i];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) { run[k] = min(run[k], bw[i][k]); run[3 + k] = max(run[3 + k], bw[i][3 + k]); }
+                    cc += bc[i];
                     float f[6];
                     ibox_to_float(run, f);
                     sa_run[i] = sah_sa(f);
@@ -1189,7 +1220,7 @@ __device__ __forceinline__ void sah_small_task(const SahArgs& a, SmallSmem& S, u
                 S.skind[s] = kind; S.splane[s] = plane; S.snl[s] = nl;
                 // parent descriptor (SharedTaskBuilder.cu:544-558)
                 float pb[6];
-                ibox_to_float(&S.sbox[cur][s][0], pb);
+                small_box_to_float(S.sbox[cur], s, pb);
                 sah_put_node(a.nodes + parent, pb, (uint32_t)(bias + 2 * (int)(base + s + nl)), 2u, RT_CHILD_BOX);
             }
         }
@@ -1211,10 +1242,10 @@ __device__ __forceinline__ void sah_small_task(const SahArgs& a, SmallSmem& S, u
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const int ctr = float_to_ordered_int((b[k] + b[3 + k]) * 0.5f);
-                atomicMin(&S.sbox[nxt][cs][k], float_to_ordered_int(b[k]));
-                atomicMax(&S.sbox[nxt][cs][3 + k], float_to_ordered_int(b[3 + k]));
-                atomicMin(&S.sbox[nxt][cs][6 + k], ctr);
-                atomicMax(&S.sbox[nxt][cs][9 + k], ctr);
+                atomicMin(&S.sbox[nxt][k][cs], float_to_ordered_int(b[k]));
+                atomicMax(&S.sbox[nxt][3 + k][cs], float_to_ordered_int(b[3 + k]));
+                atomicMin(&S.sbox[nxt][6 + k][cs], ctr);
+                atomicMax(&S.sbox[nxt][9 + k][cs], ctr);
             }
         }
         // push every item to its new lane (a permutation inside each sub-task; inactive lanes keep theirs)
