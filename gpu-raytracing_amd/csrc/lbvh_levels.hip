@@ -111,6 +111,7 @@ struct LevelArgs {
     // arrive[k][block] (k >= 1) tickets taken by the level k-1 blocks that feed it (zero before the launch);
     // sub_cnt / sub_rec [k][block][kUpperFan / kSubFan] scratch of the fallback path
     uint32_t num_levels;
+    uint32_t fan;                // previous-level blocks one upper-level block folds (<= kUpperFan)
     uint32_t blocks[kMaxLevels];
     uint32_t* cnt[kMaxLevels];
     uint32_t* rec[kMaxLevels];
@@ -796,8 +797,8 @@ __global__ __launch_bounds__(1024) void lbvh_upper_kernel(LevelArgs a)
             // the barrier lets the other waves read the group's records
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            const uint32_t grp = blk / kUpperFan;
-            const uint32_t nb_in = min(kUpperFan, a.blocks[lvl - 1] - grp * kUpperFan);
+            const uint32_t grp = blk / a.fan;
+            const uint32_t nb_in = min(a.fan, a.blocks[lvl - 1] - grp * a.fan);
             if (tid == 0) {
                 const uint32_t ticket = __hip_atomic_fetch_add(a.arrive[lvl] + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const bool last = ticket == nb_in - 1;
@@ -812,8 +813,8 @@ __global__ __launch_bounds__(1024) void lbvh_upper_kernel(LevelArgs a)
             if (*flag == 0) return;
             blk = grp;
         }
-        const uint32_t first = blk * kUpperFan;
-        const uint32_t nb = min(kUpperFan, a.blocks[lvl - 1] - first);
+        const uint32_t first = blk * a.fan;
+        const uint32_t nb = min(a.fan, a.blocks[lvl - 1] - first);
         const uint32_t* src_cnt = a.cnt[lvl - 1] + first;
         const uint32_t* src_rec = a.rec[lvl - 1] + (size_t)first * kMaxOpen * kRecDwords;
         uint32_t* out_cnt = a.cnt[lvl] + blk;
@@ -877,6 +878,23 @@ __global__ void lbvh_tiny_kernel(const rt_triangle_pair* leaves, rt_node* nodes,
     }
 }
 
+#ifdef RT_SORT_TUNING
+#include <cstdlib>
+#endif
+// Blocks of the previous level one upper-level block folds: 48 while that needs no more levels than 64 does (about 10 open
+// roots per leaf block on real scenes: 48 blocks keep a pass inside the small range-search tables, <= 511 roots).  Measured
+// (tools/lbvh_fan_sweep.sh, upper kernel at 1M / 10M triangles): fan 16: 25.9 / 104 us, 32: 27.4 / 61.0, 48: 24.9 / 55.0,
+// 64: 25.2 / 60.2.
+static uint32_t lbvh_upper_fan(uint32_t leaf_blocks)
+{
+    auto levels = [](uint32_t b, uint32_t fan) { uint32_t l = 1; while (b > 1 && l < kMaxLevels) { b = (b + fan - 1) / fan; l++; } return l; };
+#ifdef RT_SORT_TUNING
+    if (const char* e = getenv("RT_LBVH_FAN")) { const int f = atoi(e); if (f >= 2 && f <= (int)kUpperFan) return (uint32_t)f; }
+#endif
+    const uint32_t want = levels(leaf_blocks, kUpperFan);
+    return levels(leaf_blocks, 48u) == want ? 48u : kUpperFan;
+}
+
 LevelPlan lbvh_level_plan(uint32_t n)
 {
     LevelPlan p;
@@ -885,13 +903,14 @@ LevelPlan lbvh_level_plan(uint32_t n)
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     uint32_t blocks = (n + kLeafCap - 1) / kLeafCap;
     if (blocks == 0) blocks = 1;
+    p.fan = lbvh_upper_fan(blocks);
     // the arrival counters of all levels first, contiguous: the build's init kernel zeroes [arrive_off, +arrive_bytes)
     p.sink_off = take(64);
     p.arrive_off = off;
     {
         uint32_t b = blocks;
         size_t words = 0;
-        for (uint32_t k = 0; k < kMaxLevels; k++) { words += b; if (b == 1) break; b = (b + kUpperFan - 1) / kUpperFan; }
+        for (uint32_t k = 0; k < kMaxLevels; k++) { words += b; if (b == 1) break; b = (b + p.fan - 1) / p.fan; }
         p.arrive_bytes = words * 4;
         off += (p.arrive_bytes + 255) / 256 * 256;
     }
@@ -907,7 +926,7 @@ LevelPlan lbvh_level_plan(uint32_t n)
         p.sub_cnt_off[k] = k ? take((size_t)blocks * kSubs * 4) : 0;
         p.sub_rec_off[k] = k ? take((size_t)blocks * kSubs * kMaxOpen * kRecDwords * 4) : 0;
         if (blocks == 1 || p.num_levels == kMaxLevels) break;
-        blocks = (blocks + kUpperFan - 1) / kUpperFan;
+        blocks = (blocks + p.fan - 1) / p.fan;
     }
     p.total = off;
     return p;
@@ -945,6 +964,7 @@ hipError_t launch_lbvh_levels(const rt_triangle* tris, const uint32_t* codes, co
         a.status = status;
         a.sink = reinterpret_cast<uint32_t*>(base + p.sink_off);
         a.num_levels = p.num_levels;
+        a.fan = p.fan;
         for (uint32_t k = 0; k < kMaxLevels; k++) {
             const bool on = k < p.num_levels;
             a.blocks[k] = on ? p.blocks[k] : 0;

@@ -66,6 +66,7 @@ constexpr uint32_t kMaxLevels = 6;    // 2^28 leaves -> 2^19 blocks -> 8192 -> 1
 
 struct LevelPlan {
     uint32_t num_levels;
+    uint32_t fan;                    // previous-level blocks folded by one upper-level block (<= kUpperFan)
     uint32_t blocks[kMaxLevels];
     size_t cnt_off[kMaxLevels];      // uint32[blocks]
     size_t rec_off[kMaxLevels];      // uint32[blocks][kMaxOpen][kRecDwords]
