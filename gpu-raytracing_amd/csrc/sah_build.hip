@@ -50,7 +50,7 @@ struct SahSmall { uint32_t start, end, parent_idx, flags; };   // flags bit0 top
 struct SahHeader {
     int gp[6], gc[6];                  // scene primitive / centroid bounds, ordered ints
     uint32_t status[8];                // [0] error flags, [1] number of items L, [2] leaf records, [3] split budget asked
-    uint32_t small_count, pad[3];
+    uint32_t small_count, live_report, pad[2];   // live_report: tasks still alive after the last batch of levels (sah_patch_top_kernel)
     uint32_t cell_count[kSahCells], cell_start[kSahCells], cell_task[kSahCells];
     int cell_p[kSahCells][6], cell_c[kSahCells][6];
     uint32_t level_count[kSahMaxLevels];
@@ -1279,10 +1279,11 @@ __global__ __launch_bounds__(kSmallWaves * 64) void sah_small_kernel(SahArgs a, 
 
 // top-tree leaves: copy child / count / type of the cell's sub-root (SharedTaskBuilder.cu:422-446; the reference
 // forces type Box, which breaks a cell that holds a single leaf -- the type is copied here)
-__global__ void sah_patch_top_kernel(SahArgs a, int records_in_status2)
+__global__ void sah_patch_top_kernel(SahArgs a, int records_in_status2, uint32_t lvl)
 {
     const uint32_t s = threadIdx.x;
     if (s == 0 && !records_in_status2) a.H->status[2] = a.H->status[1];   // without splits: one item per leaf record
+    if (s == 0) a.H->live_report = a.H->level_count[lvl];                 // next to the status words: the host reads both with ONE copy
     if (s >= 2 * kSahCells) return;
     rt_node* nd = a.nodes + s;
     if ((nd->w28 >> 29) != RT_CHILD_BOX || (nd->w12 >> 29) != 0) return;
@@ -1433,13 +1434,16 @@ hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, boo
         // cell's root is a level-0 task (or a small task queued by sah_roots_kernel), and the first batch runs at least
         // three levels plus the small-task kernel, so every cell root has written its descriptor before this launch; later
         // batches only finish tasks deeper in the trees and find nothing left to patch.
-        sah_patch_top_kernel<<<1, 128, 0, st>>>(a, splits ? 1 : 0);
-        uint32_t live = 0, hdr[9] = {0};   // status[0..7] and small_count are adjacent in SahHeader
-        static_assert(offsetof(SahHeader, small_count) == offsetof(SahHeader, status) + 32, "one copy reads both");
-        e = hipMemcpyAsync(&live, &a.H->level_count[lvl], 4, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(hdr, &a.H->status[0], sizeof hdr, hipMemcpyDeviceToHost, st);
+        sah_patch_top_kernel<<<1, 128, 0, st>>>(a, splits ? 1 : 0, lvl);
+        // status[0..7], small_count and live_report are adjacent in SahHeader: ONE device-to-host copy (two copies into
+        // pageable host memory cost a host round trip each: 19 us between them in round 3's timeline)
+        uint32_t hdr[10] = {0};
+        static_assert(offsetof(SahHeader, small_count) == offsetof(SahHeader, status) + 32 &&
+                      offsetof(SahHeader, live_report) == offsetof(SahHeader, status) + 36, "one copy reads all three");
+        e = hipMemcpyAsync(hdr, &a.H->status[0], sizeof hdr, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) return e;
+        const uint32_t live = hdr[9];
         small_done = hdr[8];
         if (status0) *status0 = hdr[0];
         if (levels_run) *levels_run = lvl;           // (also on the error returns below)
