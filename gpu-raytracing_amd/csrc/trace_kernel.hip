@@ -612,7 +612,14 @@ __global__ __launch_bounds__(kTraceWaves * 64, (RENDER <= 2 || RENDER == kRender
 void trace_kernel(TraceParams p)
 {
     __shared__ uint32_t stack_lds[kTraceWaves][kStackLds][64];
+    __shared__ unsigned long long csum[4];   // the workgroup's test counters (see the end of the kernel)
+    __shared__ uint32_t carrive;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (p.counters) {                         // (kernel argument: the same for every thread)
+        if (threadIdx.x < 4) csum[threadIdx.x] = 0ull;
+        if (threadIdx.x == 4) carrive = 0u;
+        __syncthreads();
+    }
 
     // XCD-aware remap: hardware deals workgroup b to XCD b % 8; give XCD x a contiguous run of tiles.
     // Tile order vs XCDs: hardware deals workgroup b to XCD b % 8.  XCD x takes chunks of kXcdChunk consecutive workgroups
@@ -670,12 +677,26 @@ void trace_kernel(TraceParams p)
         reinterpret_cast<uint32_t*>(p.rgba8)[(size_t)out_y * p.w + x] = px;
     }
     if (p.counters) {
+        // The four counters are ONE 32-byte target for every wave of the frame, and same-address device atomics queue at the
+        // memory side at ~11 ns each: four atomics per wave (round 2) were 130 k queued atomics = 1.4 ms per 1080p frame --
+        // more than the whole frame through a SAH tree (rt_cli, which passes counters like the reference's Trace() does,
+        // showed it; bench.py times its frames without counters).  Now the workgroup's waves add into LDS, and the LAST
+        // wave to finish (an LDS arrival count: no barrier, nobody waits) issues one atomic instruction whose four lanes
+        // carry the four sums: one memory-side request per workgroup.
         const uint32_t bsum = wave_sum_u32(box_acc), tsum = wave_sum_u32(tri_acc);  // <= 64 * 2^26: no overflow per wave
-        if (lane == 0 && (bsum | tsum)) {
-            atomicAdd(&p.counters[0], (unsigned long long)bsum);
-            atomicAdd(&p.counters[1], (unsigned long long)tsum);
-            atomicAdd(&p.counters[2], (unsigned long long)steps[0]);  // wave-level box-phase steps (profiling)
-            atomicAdd(&p.counters[3], (unsigned long long)steps[1]);  // wave-level leaf-phase steps
+        uint32_t last = 0;
+        if (lane == 0) {
+            atomicAdd(&csum[0], (unsigned long long)bsum);
+            atomicAdd(&csum[1], (unsigned long long)tsum);
+            atomicAdd(&csum[2], (unsigned long long)steps[0]);  // wave-level box-phase steps (profiling)
+            atomicAdd(&csum[3], (unsigned long long)steps[1]);  // wave-level leaf-phase steps
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            last = atomicAdd(&carrive, 1u) == (uint32_t)kTraceWaves - 1u ? 1u : 0u;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        if (__builtin_amdgcn_readfirstlane((int)last) && lane < 4) {
+            const unsigned long long v = *(volatile unsigned long long*)&csum[lane];
+            if (v) atomicAdd(&p.counters[lane], v);
         }
     }
 }

@@ -6,6 +6,9 @@
 //   rt_cli <file.obj> [--type sah|bottom-up|hybrid] [--pairs] [--splits] [--render depth|boxtests|tritests|material|lods|diffuse|texture|texturelit|shadows]
 //          [--width W] [--height H] [--spp N] [--yaw Y --pitch P --pos X Y Z] [--out frame.ppm] [--frames K]
 //          [--path "<ev>,<ev>,..."] [--rebuild] [--gpus N [--partition bands|strips|auto]]
+//   rt_cli - --grid G [--camera a|b] ...      (argv[1] stays the scene slot, as in the reference) the bench's synthetic scene: grid_mesh(G, 1) of
+//                                             gpu-raytracing_amd/scenes.py (G = 708: 1,002,528 triangles) and its camera A
+//                                             ("top-down") or B ("oblique"), SURVEY 8(d) -- the C++ host at the headline size
 //
 // --gpus N: the frame is traced by N GPUs of this node from this ONE process (MultiGpu.h): replicated build per device,
 // one row band (or interleaved strips) per device, one grouped RCCL send/recv per frame into device 0, counters summed by
@@ -37,6 +40,49 @@
 #include "MultiGpu.h"
 #include "Tracer.h"
 #include "Utilities.h"
+
+// grid_mesh(G, seed) of gpu-raytracing_amd/scenes.py: a height field of G x G cells, two triangles per cell, heights from an
+// integer hash (libm-free, bit-identical to the Python generator); flat normals, one material
+static uint32_t PcgHash(uint32_t x)
+{
+    const uint32_t state = x * 747796405u + 2891336453u;
+    const uint32_t word = ((state >> ((state >> 28) + 4u)) ^ state) * 277803737u;
+    return (word >> 22) ^ word;
+}
+static Scene GridMesh(uint32_t G, uint32_t seed)
+{
+    Scene scene;
+    scene.triangles.resize((size_t)G * G * 2);
+    scene.attributes.resize(scene.triangles.size());
+    auto P = [&](uint32_t i, uint32_t j) {
+        const uint32_t key = i + 0x9E3779B9u * j + seed;
+        return make_vec3((float)i, 2.0f * ((float)(PcgHash(key) >> 8) * (1.0f / 16777216.0f)), (float)j);
+    };
+    size_t t = 0;
+    scene.aabb = AABB{make_vec3(FLT_MAX), make_vec3(-FLT_MAX)};
+    for (uint32_t j = 0; j < G; j++)
+        for (uint32_t i = 0; i < G; i++) {
+            const vec3 p00 = P(i, j), p10 = P(i + 1, j), p01 = P(i, j + 1), p11 = P(i + 1, j + 1);
+            const vec3 tri[2][3] = {{p00, p10, p01}, {p10, p11, p01}};
+            for (int k = 0; k < 2; k++, t++) {
+                Triangle& T = scene.triangles[t];
+                T.v0 = tri[k][0]; T.v1 = tri[k][1]; T.v2 = tri[k][2];
+                const vec3 nrm = normalize(cross(T.v1 - T.v0, T.v2 - T.v1));      // FileIO.cpp:88-93
+                Attributes& A = scene.attributes[t];
+                memset(&A, 0, sizeof A);
+                for (int c = 0; c < 3; c++) A.normal[c] = nrm;
+                A.material_id = 0;
+                for (int c = 0; c < 3; c++) scene.aabb = Combine(scene.aabb, tri[k][c]);
+            }
+        }
+    scene.library.AddMaterial("grid");
+    scene.library.materials[0].ambient = make_vec3(0.4f, 0.15f, 0.1f);
+    scene.library.materials[0].diffuse = make_vec3(0.8f, 0.3f, 0.2f);
+    scene.library.materials[0].specular = make_vec3(0.5f);
+    scene.library.materials[0].specular_exp = 10.0f;
+    scene.light = scene.aabb.Centre();
+    return scene;
+}
 
 static RenderType ParseRender(const std::string& s)
 {
@@ -130,6 +176,8 @@ int main(int argc, char** argv)
     bool rebuild = false;
     int gpus = 0;                                              // 0: the single-device path of the reference
     Partition partition = Partition::kAuto;
+    uint32_t grid = 0;                                         // --grid G: synthetic scene instead of argv[1]
+    char grid_camera = 0;
     bool have_pos = false, have_yaw = false, have_pitch = false;
     vec3 pos{0, 0, 0};
     float yaw = 0, pitch = 0;
@@ -145,6 +193,8 @@ int main(int argc, char** argv)
         else if (a == "--path") { path = next(1); i++; }
         else if (a == "--rebuild") { rebuild = true; }
         else if (a == "--gpus") { gpus = atoi(next(1)); i++; }
+        else if (a == "--grid") { grid = (uint32_t)atoi(next(1)); i++; }
+        else if (a == "--camera") { grid_camera = next(1)[0]; i++; }
         else if (a == "--partition") {
             const std::string v = next(1);
             partition = v == "bands" ? Partition::kBands : (v == "strips" ? Partition::kStrips : Partition::kAuto);
@@ -155,7 +205,8 @@ int main(int argc, char** argv)
         else if (a == "--pos") { pos = make_vec3((float)atof(next(1)), (float)atof(next(2)), (float)atof(next(3))); have_pos = true; i += 3; }
     }
 
-    Scene scene = LoadOBJFromFile(g_filename);
+    Scene scene = grid ? GridMesh(grid, 1) : LoadOBJFromFile(g_filename);
+    if (grid) printf("grid_mesh(%u, 1): %zu triangles\n", grid, scene.triangles.size());
     const unsigned n = (unsigned)scene.triangles.size();
     const bool hybrid = args.build_type == kHybrid, sah = args.build_type == kSAH;
     const unsigned root_count = sah ? 1 : 2;              // main.cu:223
@@ -163,6 +214,12 @@ int main(int argc, char** argv)
     MemoryBuffer<Camera> camera(1);
     memset(camera.data(), 0, sizeof(Camera));
     InitialiseCamera(camera[0], scene.aabb);
+    if (grid && grid_camera) {   // scenes.py camera_a / camera_b; max_depth = 1.5 G as Camera.cu:79 would give
+        const float Gf = (float)grid;
+        if (grid_camera == 'b') { camera[0].position = make_vec3(-0.3f * Gf, 0.5f * Gf, -0.3f * Gf); camera[0].yaw = -0.8f; camera[0].pitch = 0.3f; }
+        else { camera[0].position = make_vec3(Gf / 2, 0.45f * Gf, Gf / 2); camera[0].yaw = 0.0f; camera[0].pitch = 1.5f; }
+        camera[0].max_depth = 1.5f * Gf;
+    }
     if (have_pos) camera[0].position = pos;
     if (have_yaw) camera[0].yaw = yaw;
     if (have_pitch) camera[0].pitch = pitch;
