@@ -23,8 +23,10 @@
 //     per workgroup, 9 on average on the bench mesh -- and the next level (64x fewer blocks) treats
 //     those as its leaves;
 //   * at the leaf level every completed node lies in the block's own index range, so the block's node
-//     pairs are assembled in LDS and written with one coalesced sweep (the scattered per-merge stores
-//     made the kernel vector-memory-issue bound: 70 store instructions per wave);
+//     pairs are assembled in LDS and written in one sweep of 64-byte pieces (the scattered per-merge
+//     stores made the kernel vector-memory-issue bound: 70 store instructions per wave).  The staged
+//     pair of a node doubles as the waiting place of its children (leaf_pass): LDS per leaf decides how
+//     many workgroups share a CU, and those are what hides one workgroup's climb;
 //   * two launches build the whole hierarchy: the leaf level, then ALL upper levels: when a workgroup
 //     has written its block's open roots (write-through stores) it takes a ticket on the counter of
 //     the next level's block (one relaxed device atomic); the workgroup that takes the LAST ticket of a
@@ -38,16 +40,14 @@
 //     two children's boxes as range unions from sparse tables of boxes, and derives its Karras index, its
 //     parent and its side from the range -- no node waits for another.  A climb lasts as long as the
 //     deepest path of its tree (16 - 22 dependent merges of about 0.85 us each in these passes); the table
-//     pass takes 7 - 12 us whatever the tree looks like.  The climb (level_pass) is what the leaf level
-//     runs -- there the data movement, not the climb, is most of the time -- and the fallback for larger
-//     upper passes.
+//     pass takes 7 - 12 us whatever the tree looks like.  The climb is what the leaf level runs (leaf_pass)
+//     -- there the data movement, not the climb, is most of the time -- and the fallback for larger upper
+//     passes (level_pass).
 //
 // Node words: w28 = child:29|type:3 and the box of a slot are written by the workgroup that completes
 // the OWNING node; w12 = parent:29|count:3 of a pair is written by whoever completes the pair's parent
 // (it knows the parent slot; the counts travel with the segment as 2 bits).  Every dword of every
 // slot is written exactly once, so no write ordering between threads is needed.
-#include <type_traits>
-
 #include "rt_device.hpp"
 #include "rt_launch.hpp"
 #include "rt_pairing.hpp"
@@ -120,30 +120,22 @@ struct LevelArgs {
     uint32_t* sub_rec[kMaxLevels];
 };
 
-template <uint32_t CAP_, uint32_t NT_, bool STAGE_>
-struct LevelCfgT {
-    static constexpr uint32_t CAP = CAP_;
-    static constexpr uint32_t NT = NT_;                       // threads of the workgroup
+// LDS carve of the climbing pass (dwords)
+struct UpperCfg {
+    static constexpr uint32_t CAP = kCap;
+    static constexpr uint32_t NT = 1024;                      // threads of the workgroup
     static constexpr uint32_t PER = (CAP + 1 + NT - 1) / NT;  // boundaries per thread in the final compaction
-    // LDS carve (dwords)
     static constexpr uint32_t oDl = 0;                 // int   [CAP+1]  delta at boundary b
-    static constexpr uint32_t oBnd = oDl + CAP + 4;    // int   [CAP+1]  last leaf left of boundary b (upper passes only)
-    static constexpr uint32_t oLock = oBnd + (STAGE_ ? 0 : CAP + 4);  // u32   [CAP+1]
+    static constexpr uint32_t oBnd = oDl + CAP + 4;    // int   [CAP+1]  last leaf left of boundary b
+    static constexpr uint32_t oLock = oBnd + CAP + 4;  // u32   [CAP+1]
     static constexpr uint32_t oRange = oLock + CAP + 4;  // u32 [CAP]  sf:11 | sl:11 | cc:2 | (delta at the far end + 1):7
     static constexpr uint32_t oDesc = oRange + CAP;
     static constexpr uint32_t oBox = oDesc + CAP;      // float [6][CAP]
-    static constexpr uint32_t oAbs = oBox + 6 * CAP;   // u32 [CAP]  upper passes: the leaf index at the segment's far end
-    static constexpr uint32_t oWs = oAbs + (STAGE_ ? 0 : CAP);    // scan workspace [0, 32), hand-off flag [32], prefix table [40, 40 + 65)
-    static constexpr uint32_t oStage = oWs + 40 + kPrefSlots + 8;   // leaf pass only: the block's node pairs, 16 dwords each
-    static constexpr uint32_t oSink = oWs + 40;   // leaf pass only (it has no prefix table): 16 dwords nobody reads
-    static constexpr uint32_t kDwords = oStage + (STAGE_ ? 16 * CAP : 0);
-    static constexpr size_t kBytes = (size_t)kDwords * 4;
+    static constexpr uint32_t oAbs = oBox + 6 * CAP;   // u32 [CAP]  the leaf index at the segment's far end
+    static constexpr uint32_t oWs = oAbs + CAP;        // scan workspace [0, 32), hand-off flag [32], prefix table [40, 40 + 65)
+    static constexpr uint32_t kDwords = oWs + 40 + kPrefSlots + 8;
+    static constexpr size_t kBytes = (size_t)kDwords * 4;   // 90 KB: the upper levels run a handful of workgroups
 };
-typedef LevelCfgT<kLeafCap, kLeafThreads, true> LeafCfg;   // 52.5 KB of LDS (32 KB of it the node staging area): three 512-thread workgroups per CU
-typedef LevelCfgT<kCap, 1024, false> UpperCfg;             // 90 KB: the upper levels run a handful of workgroups
-// LDS is handed out in 1280-byte granules (160 KB / 128): 42 granules per leaf workgroup, 3 x 42 <= 128 -- 64 bytes more
-// and only two fit (measured: the kernel's run time went up by 15 % although every workgroup was faster)
-static_assert((LeafCfg::kBytes + 1279) / 1280 * 3 <= 128, "three leaf workgroups per CU");
 static_assert(kCap <= 2048, "a deposited range packs two 11-bit segment indices");
 
 // Hand-off stores: write-through at agent scope (`sc1`), so that the records a workgroup leaves for the next level are
@@ -167,6 +159,12 @@ __device__ __forceinline__ void store_sc1(uint32_t* p, uint32_t v)
 {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// streaming store (global_store_dwordx4 ... nt) of 16 bytes
+__device__ __forceinline__ void store_stream(uint4* p, const uint4& q)
+{
+    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(u4v{q.x, q.y, q.z, q.w}, reinterpret_cast<u4v*>(p));
+}
 
 __device__ __forceinline__ int delta_adjacent(const uint32_t* __restrict__ codes, int g, uint32_t n)
 {
@@ -176,16 +174,15 @@ __device__ __forceinline__ int delta_adjacent(const uint32_t* __restrict__ codes
     return c0 == c1 ? 32 + __clz((uint32_t)g ^ (uint32_t)(g + 1)) : __clz(c0 ^ c1);
 }
 
-// One pass: agglomerate S segments (LEAF: the leaves [B0, B0 + S) of this block; else the open roots of the `nb`
-// source blocks whose counts / records start at src_cnt / src_rec) inside LDS, write every node that completes and
-// emit what stays open to (out_cnt, out_rec).  All 1024 threads of the workgroup call it together.
-template <bool LEAF>
-__device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, uint32_t n, uint32_t B0, uint32_t S,
+// One pass of an upper level by climbing (the fallback of table_pass): agglomerate the S open roots of the source blocks
+// whose records start at src_rec (pref[] in LDS = prefix of their counts) inside LDS, write every node that completes
+// straight to memory and emit what stays open to (out_cnt, out_rec).  All 1024 threads of the workgroup call it together.
+__device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, uint32_t n, uint32_t S,
                                            const uint32_t* src_rec, uint32_t* out_cnt, uint32_t* out_rec, uint32_t so = 0)
 {
-    using C = typename std::conditional<LEAF, LeafCfg, UpperCfg>::type;
+    using C = UpperCfg;
     (void)so;
-    RT_STAMP(LEAF ? 0 : 1, so);
+    RT_STAMP(1, so);
     constexpr uint32_t NT = C::NT;
     int* dl = reinterpret_cast<int*>(smem + C::oDl);
     int* bnd = reinterpret_cast<int*>(smem + C::oBnd);
@@ -195,10 +192,11 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
     float* s_box = reinterpret_cast<float*>(smem + C::oBox);
     uint32_t* s_abs = smem + C::oAbs;
     uint32_t* ws = smem + C::oWs;            // [0..17) scan scratch
-    const uint32_t* pref = smem + C::oWs + 40;  // [0..64] prefix of the source blocks' counts (upper passes)
+    const uint32_t* pref = smem + C::oWs + 40;  // [0..64] prefix of the source blocks' counts
+    uint32_t* sink = a.sink;
     const uint32_t tid = threadIdx.x;
 
-    // record of local segment s of an upper pass: source block = the last one whose prefix is <= s
+    // record of local segment s: source block = the last one whose prefix is <= s
     auto rec_ptr = [&](uint32_t s) -> const uint32_t* {
         uint32_t pb = 0;
 #pragma unroll
@@ -206,19 +204,9 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
         return src_rec + ((size_t)pb * kMaxOpen + (s - pref[pb])) * kRecDwords;
     };
 
-    // Leaf pass: every node this block completes has its Karras index inside the block's leaf range, so the block's
-    // node pairs are assembled in LDS (stage[pair - B0][16 dwords]) and leave in ONE coalesced sweep at the end: 4 x
-    // 16-byte stores per pair instead of the ~12 scattered store instructions per merge that made this kernel bound
-    // by vector-memory instruction issue (70 store instructions per wave, SQ_WAIT_INST_ANY 47 %: profiles/r02_build_pmc.txt;
-    // a wave store costs per lane whatever its width: profiles/r02_ta_microbench.txt).
-    // dword 7 (w28 of slot 0: child | type, never 0 for a real slot) doubles as the "pair was completed here" marker.
-    uint32_t* stage = smem + C::oStage;
-    uint32_t* sink = LEAF ? smem + C::oSink : a.sink;
-    if (LEAF) {
-        for (uint32_t j = tid; j < C::CAP; j += NT) stage[j * 16 + 7] = 0u;
-    } else {
-        // node addresses of this pass are formed from the records: check them all first (this climb is the fallback of the
-        // upper levels; the extra sweep over the records costs nothing that matters)
+    {
+        // node addresses of this pass are formed from the records: check them all first (the extra sweep over the records
+        // costs nothing that matters here)
         bool bad = false;
         for (uint32_t s0 = tid; s0 < S; s0 += NT) {
             const uint32_t* r = rec_ptr(s0);
@@ -235,9 +223,7 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
     }
     for (uint32_t b = tid; b <= S; b += NT) {
         lock[b] = kLockEmpty;
-        if (LEAF) {
-            dl[b] = S ? delta_adjacent(a.codes, (int)B0 + (int)b - 1, n) : -1;
-        } else if (S == 0) {
+        if (S == 0) {
             dl[b] = -1;
             bnd[b] = -1;
         } else {
@@ -249,64 +235,13 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
         }
     }
     __syncthreads();
-    RT_STAMP(LEAF ? 0 : 1, so + 1);
+    RT_STAMP(1, so + 1);
 
     for (uint32_t s0 = tid; s0 < S; s0 += NT) {
         uint32_t sf = s0, sl = s0, desc, cc;
-        uint32_t fabs = 0, labs = 0;   // upper passes: first / last leaf under this segment
+        uint32_t fabs, labs;   // first / last leaf under this segment
         float bx[6];
-        if (LEAF) {
-            // GenerateTriangles (BottomUpBuilder.cu:287-312) fused: gather the triangle, emit the
-            // 64-byte leaf in sorted order (ids defined), keep its box in registers.
-            const uint32_t i = B0 + s0;
-            uint32_t sv = a.sorted_idx[i];
-            uint32_t src = sv & 0x7FFFFFFFu;
-            // the gather address comes from memory: never past the triangle array (a quad leaf also reads triangle src + 1)
-            if (src + (sv >> 31) >= a.n) {
-                atomicOr(a.status, kErrSortedIndex);
-                sv = src = 0u;
-            }
-            float v[9];
-            load_tri9(a.tris + (size_t)src * 9, v);   // 36 bytes at a 4-byte-aligned address: 2 x 16-byte loads + 1 dword
-            uint4* out = reinterpret_cast<uint4*>(a.leaves + i);
-            float v3[3] = {v[6], v[7], v[8]};
-            if (sv >> 31) {
-                // a quad leaf (--pairs): CreateTrianglePair (Pairing.cuh:60-77): A rotated so the shared edge is
-                // (v1, v2), v3 = B's vertex off that edge; ids = (src, src+1); rotations = (rot_a, rot_b)
-                float B[9];
-                load_tri9(a.tris + (size_t)src * 9 + 9, B);
-                int ra = 0, rb = 0;
-                can_form_pair(v, B, ra, rb);
-                float r[9];
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    r[k] = ra == 1 ? v[6 + k] : (ra == 2 ? v[3 + k] : v[k]);
-                    r[3 + k] = ra == 1 ? v[k] : (ra == 2 ? v[6 + k] : v[3 + k]);
-                    r[6 + k] = ra == 1 ? v[3 + k] : (ra == 2 ? v[k] : v[6 + k]);
-                    v3[k] = rb == 2 ? B[k] : (rb == 1 ? B[3 + k] : B[6 + k]);
-                }
-#pragma unroll
-                for (int k = 0; k < 9; k++) v[k] = r[k];
-                out[0] = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), src);
-                out[1] = make_uint4(__float_as_uint(v[3]), __float_as_uint(v[4]), __float_as_uint(v[5]), src + 1);
-                out[2] = make_uint4(__float_as_uint(v[6]), __float_as_uint(v[7]), __float_as_uint(v[8]), (uint32_t)ra | ((uint32_t)rb << 16));
-                out[3] = make_uint4(__float_as_uint(v3[0]), __float_as_uint(v3[1]), __float_as_uint(v3[2]), 0u);
-            } else {
-                // GenerateTriangles (BottomUpBuilder.cu:287-312) fused: the 64-byte leaf in sorted order (ids defined)
-                out[0] = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), src);
-                out[1] = make_uint4(__float_as_uint(v[3]), __float_as_uint(v[4]), __float_as_uint(v[5]), 0u);
-                out[2] = make_uint4(__float_as_uint(v[6]), __float_as_uint(v[7]), __float_as_uint(v[8]), 0u);
-                out[3] = make_uint4(__float_as_uint(v[6]), __float_as_uint(v[7]), __float_as_uint(v[8]), 0u);
-            }
-            // GenerateAABBs leaf box (BottomUpBuilder.cu:259-267; v3 only widens it for a quad, it equals v2 otherwise)
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                bx[k] = fminf(fminf(fminf(v[k], v[3 + k]), v[6 + k]), v3[k]);
-                bx[3 + k] = fmaxf(fmaxf(fmaxf(v[k], v[3 + k]), v[6 + k]), v3[k]);
-            }
-            desc = (i & kIndexMask) | ((uint32_t)RT_CHILD_TRI << 29);
-            cc = 0;
-        } else {
+        {
             const uint32_t* r = rec_ptr(s0);
             const uint4 r0 = reinterpret_cast<const uint4*>(r)[0];
             const uint4 r1 = reinterpret_cast<const uint4*>(r)[1];
@@ -322,7 +257,7 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
         // The climb is a chain of dependent LDS round trips (one workgroup's whole pass lasts as long as its deepest
         // path), so a step makes only two: deposit + exchange, then the sibling's state.  Everything else a step needs
         // travels in registers or in the deposit: the deltas at the two ends of the range (the far one is part of the
-        // deposit), and in the upper passes the leaf indices at the two ends.
+        // deposit) and the leaf indices at the two ends.
         int ldl = dl[sf], rdl = dl[sl + 1];
         while (true) {
             if (ldl < 0 && rdl < 0) break;  // covers every leaf: the finished root
@@ -337,7 +272,7 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
             s_desc[s0] = desc;
 #pragma unroll
             for (int k = 0; k < 6; k++) s_box[k * C::CAP + s0] = bx[k];
-            if (!LEAF) s_abs[s0] = pick(fabs, labs);
+            s_abs[s0] = pick(fabs, labs);
             // my state is in LDS before the exchange makes me findable: the DS operations of one wave are performed in
             // issue order, so the compiler must keep the order and the hardware does
             asm volatile("" ::: "memory");
@@ -348,7 +283,7 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
 
             const uint32_t orange = s_range[other];
             const uint32_t odesc = s_desc[other], occ = (orange >> 22) & 3u;
-            const uint32_t oabs = LEAF ? 0u : s_abs[other];
+            const uint32_t oabs = s_abs[other];
             const int ofar = (int)(orange >> 24) - 1;
             float ob[6];
 #pragma unroll
@@ -364,15 +299,14 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
             // codes inside the range agree on more bits than either delta); a LEFT child iff the left one is smaller
             const uint32_t lm = (uint32_t)((far - ofar) >> 31) ^ ~gm;   // all ones: left child -> index = last leaf
             const uint32_t nsf = pick(sf, osf), nsl = pick(osl, sl);
-            const uint32_t fP = LEAF ? B0 + nsf : pick(fabs, oabs);
-            const uint32_t lP = LEAF ? B0 + nsl : pick(oabs, labs);
+            const uint32_t fP = pick(fabs, oabs);
+            const uint32_t lP = pick(oabs, labs);
             const uint32_t idx = is_root ? 0u : (fP ^ ((lP ^ fP) & lm));  // Karras index of the new node
 
             const bool mbox = (desc >> 29) == RT_CHILD_BOX, obox = (odesc >> 29) == RT_CHILD_BOX;
             // the new node's pair, then parent:29|count:3 of the children's own pairs (BottomUpBuilder.cu:204-213, :265,
-            // :282).  Leaf pass: into the staging area (the children's pairs were completed in this block too); upper
-            // passes: straight to memory (few nodes, indices anywhere).
-            uint32_t* nw = LEAF ? stage + (idx - B0) * 16 : reinterpret_cast<uint32_t*>(a.nodes + (size_t)idx * 2);
+            // :282), straight to memory (few nodes, indices anywhere)
+            uint32_t* nw = reinterpret_cast<uint32_t*>(a.nodes + (size_t)idx * 2);
             uint32_t* nm = nw + my * 8;
             uint32_t* no = nw + 8 - my * 8;
             nm[0] = __float_as_uint(bx[0]); nm[1] = __float_as_uint(bx[1]); nm[2] = __float_as_uint(bx[2]);
@@ -383,14 +317,12 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
             // an instruction-fetch round trip nobody hides, so the stores that only a box child needs go to a sink
             // when the child is a leaf, and the root's own parent words are written after the loop.
             {
-                uint32_t* cb = LEAF ? stage + ((desc & kIndexMask) / 2 - B0) * 16 : reinterpret_cast<uint32_t*>(a.nodes + (desc & kIndexMask));
-                uint32_t* c = mbox ? cb : sink;
+                uint32_t* c = mbox ? reinterpret_cast<uint32_t*>(a.nodes + (desc & kIndexMask)) : sink;
                 c[3] = (idx * 2 + my) | (((cc & 1u) ? 2u : 1u) << 29);
                 c[11] = (idx * 2 + my) | (((cc & 2u) ? 2u : 1u) << 29);
             }
             {
-                uint32_t* cb = LEAF ? stage + ((odesc & kIndexMask) / 2 - B0) * 16 : reinterpret_cast<uint32_t*>(a.nodes + (odesc & kIndexMask));
-                uint32_t* c = obox ? cb : sink;
+                uint32_t* c = obox ? reinterpret_cast<uint32_t*>(a.nodes + (odesc & kIndexMask)) : sink;
                 c[3] = (idx * 2 + 1 - my) | (((occ & 1u) ? 2u : 1u) << 29);
                 c[11] = (idx * 2 + 1 - my) | (((occ & 2u) ? 2u : 1u) << 29);
             }
@@ -411,28 +343,15 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
         }
         if ((ldl & rdl) < 0 && (desc >> 29) == RT_CHILD_BOX) {
             // this thread completed the root.  Q3: the reference leaves the root pair's parent undefined; defined as 0
-            uint32_t* nw = LEAF ? stage : reinterpret_cast<uint32_t*>(a.nodes);
+            uint32_t* nw = reinterpret_cast<uint32_t*>(a.nodes);
             nw[3] = ((cc & 1u) ? 2u : 1u) << 29;
             nw[11] = ((cc & 2u) ? 2u : 1u) << 29;
         }
     }
     __syncthreads();
-    RT_STAMP(LEAF ? 0 : 1, so + 2);
+    RT_STAMP(1, so + 2);
 
-    if (LEAF) {
-        // the completed pairs of this block, 16 bytes per lane, consecutive lanes on consecutive addresses.  A pair whose
-        // parent is completed at an upper level leaves with undefined w12 words (dwords 3 and 11); the upper-level
-        // kernel, which runs after this one, writes them -- as it writes every word of the pairs not completed here.
-        const uint4* st4 = reinterpret_cast<const uint4*>(stage);
-        uint4* dst = reinterpret_cast<uint4*>(a.nodes + (size_t)B0 * 2);
-#pragma unroll
-        for (uint32_t k = 0; k < 4 * C::CAP / NT; k++) {
-            const uint32_t c = tid + k * NT;          // 16-byte chunk; pair = c / 4
-            if ((stage[(c >> 2) * 16 + 7] >> 29) != 0u) dst[c] = st4[c];
-        }
-    }
-
-    RT_STAMP(LEAF ? 0 : 1, so + 3);
+    RT_STAMP(1, so + 3);
     // open roots = rendezvous points where only one child ever arrived, in boundary (= leaf) order
     uint32_t ids[C::PER];
     uint32_t mine = 0;
@@ -452,8 +371,8 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
             if (pos < kMaxOpen) {
                 const uint32_t rg = s_range[id];
                 const uint32_t osf = rg & 0x7FFu, osl = (rg >> 11) & 0x7FFu;
-                const uint32_t f = LEAF ? B0 + osf : (uint32_t)(bnd[osf] + 1);
-                const uint32_t l = LEAF ? B0 + osl : (uint32_t)bnd[osl + 1];
+                const uint32_t f = (uint32_t)(bnd[osf] + 1);
+                const uint32_t l = (uint32_t)bnd[osl + 1];
                 uint4* o = reinterpret_cast<uint4*>(out_rec + (size_t)pos * kRecDwords);
                 store_sc1(o + 0, f, l, s_desc[id], (rg >> 22) & 3u);
                 store_sc1(o + 1, __float_as_uint(s_box[0 * C::CAP + id]), __float_as_uint(s_box[1 * C::CAP + id]),
@@ -469,7 +388,263 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
         if (total > kMaxOpen) atomicOr(a.status, kErrOpenOverflow);  // cannot happen: <= 2 * depth(62) open roots
     }
     __syncthreads();   // LDS is reused by the next pass of this workgroup
-    RT_STAMP(LEAF ? 0 : 1, so + 4);
+    RT_STAMP(1, so + 4);
+}
+
+// ---- the leaf level's pass.  Same agglomeration as level_pass, laid out for occupancy: the leaf level is where the
+// bytes are (a gather of 40 bytes and 208 bytes of stores per leaf) and a workgroup alternates between memory phases and the
+// climb, so what hides the climb is other workgroups of the same CU.  LDS decides how many there are.  Here a segment's
+// waiting state IS its half of its parent's node pair: the node that splits at boundary b is staged at stage[b], the first
+// child to arrive writes its box and descriptor straight into its slot there and exchanges (range | cc | far delta, own
+// split boundary) through the 64-bit lock word of b; the second arriver gets that word back from the exchange (no second
+// LDS round trip for the range), reads the sibling's slot, writes its own, and leaves (done, Karras index) in the lock
+// word.  No separate box / descriptor / range arrays: 76 bytes of LDS per leaf instead of 104, FOUR 512-thread
+// workgroups per CU (every wave slot of the CU) instead of three, and seven LDS stores fewer on a merge's dependent chain.
+// The final sweep sends pair stage[b] to nodes[2 * index(b)]: 64-byte pieces, all inside the block's own node range.
+struct LeafCfg {
+    static constexpr uint32_t CAP = kLeafCap, NT = kLeafThreads;
+    static constexpr uint32_t PER = (CAP + 1 + NT - 1) / NT;
+    static constexpr uint32_t oDl = 0;                        // int [CAP+1] delta at boundary b
+    static constexpr uint32_t oLock = oDl + CAP + 4;          // u64 [CAP+1] exchange word of boundary b
+    static constexpr uint32_t oStage = oLock + 2 * CAP + 4;   // u32 [CAP+1][16] the pair of the node that splits at b
+    static constexpr uint32_t oWs = oStage + 16 * (CAP + 1);  // scan workspace
+    static constexpr uint32_t kDwords = oWs + 40;
+    static constexpr size_t kBytes = (size_t)kDwords * 4;
+};
+// LDS is handed out in 1280-byte granules (160 KB / 128)
+static_assert((LeafCfg::kBytes + 1279) / 1280 * 4 <= 128, "four leaf workgroups per CU");
+static_assert(LeafCfg::oLock % 2 == 0 && LeafCfg::oStage % 4 == 0, "64-bit lock words, 16-byte stage chunks");
+static_assert(kLeafCap <= 512, "a lock word packs two 9-bit leaf positions");
+constexpr unsigned long long kLock64Empty = ~0ull;
+
+__device__ __forceinline__ void leaf_pass(const LevelArgs& a, uint32_t* smem, uint32_t n, uint32_t B0, uint32_t S,
+                                          uint32_t* out_cnt, uint32_t* out_rec)
+{
+    using C = LeafCfg;
+    constexpr uint32_t NT = C::NT;
+    RT_STAMP(0, 0);
+    int* dl = reinterpret_cast<int*>(smem + C::oDl);
+    unsigned long long* lock = reinterpret_cast<unsigned long long*>(smem + C::oLock);
+    uint32_t* stage = smem + C::oStage;
+    uint32_t* ws = smem + C::oWs;
+    // stores that only a box child needs go here when the child is a leaf (dwords 3 and 11 are written): slot 0 of stage[0]
+    // is nobody's (the node that splits at the block's left edge has its left child in the previous block) and dword 11 is
+    // the parent word of its slot 1, which an upper level writes to memory, never this block
+    uint32_t* sink = stage;
+    const uint32_t tid = threadIdx.x;
+
+    for (uint32_t b = tid; b <= S; b += NT) {
+        lock[b] = kLock64Empty;
+        dl[b] = delta_adjacent(a.codes, (int)B0 + (int)b - 1, n);
+    }
+    __syncthreads();
+    RT_STAMP(0, 1);
+
+    static_assert(C::CAP == NT, "one leaf per thread");
+    const uint32_t s0 = tid, i = B0 + s0;
+    const bool act = s0 < S;
+    float bx[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (act) {
+        // GenerateTriangles (BottomUpBuilder.cu:287-312) fused: gather the triangle, emit the 64-byte leaf in sorted order
+        // (ids defined), keep its box in registers.
+        uint32_t sv = a.sorted_idx[i];
+        uint32_t src = sv & 0x7FFFFFFFu;
+        // the gather address comes from memory: never past the triangle array (a quad leaf also reads triangle src + 1)
+        if (src + (sv >> 31) >= a.n) {
+            atomicOr(a.status, kErrSortedIndex);
+            sv = src = 0u;
+        }
+        float v[9];
+        load_tri9(a.tris + (size_t)src * 9, v);   // 36 bytes at a 4-byte-aligned address: 2 x 16-byte loads + 1 dword
+        // the leaf goes to LDS first (the staging area is free until the climb starts) and leaves in the sweep below
+        uint4* out = reinterpret_cast<uint4*>(stage + s0 * 16);
+        float v3[3] = {v[6], v[7], v[8]};
+        if (sv >> 31) {
+            // a quad leaf (--pairs): CreateTrianglePair (Pairing.cuh:60-77): A rotated so the shared edge is
+            // (v1, v2), v3 = B's vertex off that edge; ids = (src, src+1); rotations = (rot_a, rot_b)
+            float B[9];
+            load_tri9(a.tris + (size_t)src * 9 + 9, B);
+            int ra = 0, rb = 0;
+            can_form_pair(v, B, ra, rb);
+            float r[9];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                r[k] = ra == 1 ? v[6 + k] : (ra == 2 ? v[3 + k] : v[k]);
+                r[3 + k] = ra == 1 ? v[k] : (ra == 2 ? v[6 + k] : v[3 + k]);
+                r[6 + k] = ra == 1 ? v[3 + k] : (ra == 2 ? v[k] : v[6 + k]);
+                v3[k] = rb == 2 ? B[k] : (rb == 1 ? B[3 + k] : B[6 + k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 9; k++) v[k] = r[k];
+            out[0] = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), src);
+            out[1] = make_uint4(__float_as_uint(v[3]), __float_as_uint(v[4]), __float_as_uint(v[5]), src + 1);
+            out[2] = make_uint4(__float_as_uint(v[6]), __float_as_uint(v[7]), __float_as_uint(v[8]), (uint32_t)ra | ((uint32_t)rb << 16));
+            out[3] = make_uint4(__float_as_uint(v3[0]), __float_as_uint(v3[1]), __float_as_uint(v3[2]), 0u);
+        } else {
+            out[0] = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), src);
+            out[1] = make_uint4(__float_as_uint(v[3]), __float_as_uint(v[4]), __float_as_uint(v[5]), 0u);
+            out[2] = make_uint4(__float_as_uint(v[6]), __float_as_uint(v[7]), __float_as_uint(v[8]), 0u);
+            out[3] = make_uint4(__float_as_uint(v[6]), __float_as_uint(v[7]), __float_as_uint(v[8]), 0u);
+        }
+        // GenerateAABBs leaf box (BottomUpBuilder.cu:259-267; v3 only widens it for a quad, it equals v2 otherwise)
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            bx[k] = fminf(fminf(fminf(v[k], v[3 + k]), v[6 + k]), v3[k]);
+            bx[3 + k] = fmaxf(fmaxf(fmaxf(v[k], v[3 + k]), v[6 + k]), v3[k]);
+        }
+    }
+    {
+        // The block's 32 KB of leaves leave as whole 128-byte lines, 16 bytes per lane on consecutive addresses.  Written by
+        // their own threads (four 16-byte stores per lane at a 64-byte stride) every store instruction touched 32 lines and
+        // completed none: 565 -> 477 us for this kernel on the 10M mesh.  Streaming stores (nt): nobody reads leaves or nodes
+        // before the build is over, and what a default-policy store leaves behind in the Infinity Cache is written back
+        // during the NEXT kernel that streams (scene_aabb of the following build: 100 -> 60 us at 10M).  nt on the strided
+        // per-thread stores was the opposite: 838 us (profiles/r03_leaf_store_experiments.txt).
+        __syncthreads();
+        const uint4* st4 = reinterpret_cast<const uint4*>(stage);
+        uint4* dst = reinterpret_cast<uint4*>(a.leaves + B0);
+#pragma unroll
+        for (uint32_t k = 0; k < 4 * C::CAP / NT; k++) {
+            const uint32_t c = tid + k * NT;
+            if ((c >> 2) < S) store_stream(dst + c, st4[c]);
+        }
+        __syncthreads();   // the climb reuses the staging area
+    }
+    if (act) {
+        uint32_t sf = s0, sl = s0, cc = 0, myb = 0;   // myb: the boundary my own node splits at (a box segment)
+        uint32_t desc = (i & kIndexMask) | ((uint32_t)RT_CHILD_TRI << 29);
+
+        // The climb: a chain of dependent LDS round trips (a workgroup's pass lasts as long as its deepest path), two per
+        // step: slot + exchange, then the sibling's slot.
+        int ldl = dl[sf], rdl = dl[sl + 1];
+        while (true) {
+            if (ldl < 0 && rdl < 0) break;  // covers every leaf: the finished root
+            // go_right (ldl < rdl): I am the LEFT child of my parent.  As a mask, so that what depends on it is bit selects
+            // (deltas lie in [-1, 63]: the difference cannot overflow)
+            const uint32_t gm = (uint32_t)((ldl - rdl) >> 31);
+            auto pick = [gm](uint32_t right, uint32_t left) { return left ^ ((right ^ left) & gm); };  // go_right ? right : left
+            const uint32_t b = pick(sl + 1, sf);
+            const int far = min(ldl, rdl);
+            const uint32_t my = gm + 1u;   // my slot of the parent's pair: 0 = left child
+
+            uint32_t* nw = stage + b * 16;
+            uint32_t* nm = nw + my * 8;
+            nm[0] = __float_as_uint(bx[0]); nm[1] = __float_as_uint(bx[1]); nm[2] = __float_as_uint(bx[2]);
+            *reinterpret_cast<uint4*>(nm + 4) = make_uint4(__float_as_uint(bx[3]), __float_as_uint(bx[4]), __float_as_uint(bx[5]), desc);
+            const unsigned long long word = (unsigned long long)(sf | (sl << 9) | (cc << 18) | ((uint32_t)(far + 1) << 20)) |
+                                            ((unsigned long long)myb << 32);
+            // my slot is in LDS before the exchange makes me findable: the DS operations of one wave are performed in issue
+            // order, so the compiler must keep the order and the hardware does
+            asm volatile("" ::: "memory");
+            const unsigned long long other = atomicExch(&lock[b], word);
+            asm volatile("" ::: "memory");
+            if (other == kLock64Empty) break;  // first at the rendezvous: the sibling will carry on
+
+            const uint32_t* no = nw + 8 - my * 8;
+            float ob[6];
+            ob[0] = __uint_as_float(no[0]); ob[1] = __uint_as_float(no[1]); ob[2] = __uint_as_float(no[2]);
+            const uint4 o4 = *reinterpret_cast<const uint4*>(no + 4);
+            ob[3] = __uint_as_float(o4.x); ob[4] = __uint_as_float(o4.y); ob[5] = __uint_as_float(o4.z);
+            const uint32_t odesc = o4.w;
+            const uint32_t orange = (uint32_t)other, omyb = (uint32_t)(other >> 32);
+            const uint32_t osf = orange & 0x1FFu, osl = (orange >> 9) & 0x1FFu, occ = (orange >> 18) & 3u;
+            const int ofar = (int)(orange >> 20) - 1;
+
+            const bool is_root = (far & ofar) < 0;       // the deltas at both ends of the merged range are -1: node 0
+            // the merged range's end deltas are (far, ofar) in my direction's order (never equal below the root: the
+            // codes inside the range agree on more bits than either delta); a LEFT child iff the left one is smaller
+            const uint32_t lm = (uint32_t)((far - ofar) >> 31) ^ ~gm;   // all ones: left child -> index = last leaf
+            const uint32_t nsf = pick(sf, osf), nsl = pick(osl, sl);
+            const uint32_t fP = B0 + nsf, lP = B0 + nsl;
+            const uint32_t idx = is_root ? 0u : (fP ^ ((lP ^ fP) & lm));  // Karras index of the new node
+            lock[b] = (unsigned long long)kLockDone | ((unsigned long long)idx << 32);
+
+            // parent:29|count:3 of the children's own pairs (BottomUpBuilder.cu:204-213, :265, :282); straight-line: a
+            // leaf child has no pair, its two stores go to the sink
+            const bool mbox = (desc >> 29) == RT_CHILD_BOX, obox = (odesc >> 29) == RT_CHILD_BOX;
+            {
+                uint32_t* c = mbox ? stage + myb * 16 : sink;
+                c[3] = (idx * 2 + my) | (((cc & 1u) ? 2u : 1u) << 29);
+                c[11] = (idx * 2 + my) | (((cc & 2u) ? 2u : 1u) << 29);
+            }
+            {
+                uint32_t* c = obox ? stage + omyb * 16 : sink;
+                c[3] = (idx * 2 + 1 - my) | (((occ & 1u) ? 2u : 1u) << 29);
+                c[11] = (idx * 2 + 1 - my) | (((occ & 2u) ? 2u : 1u) << 29);
+            }
+
+            sf = nsf;
+            sl = nsl;
+            ldl = (int)pick((uint32_t)ldl, (uint32_t)ofar);
+            rdl = (int)pick((uint32_t)ofar, (uint32_t)rdl);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                bx[k] = fminf(bx[k], ob[k]);
+                bx[3 + k] = fmaxf(bx[3 + k], ob[3 + k]);
+            }
+            desc = ((idx * 2) & kIndexMask) | ((uint32_t)RT_CHILD_BOX << 29);
+            cc = (mbox ? 1u << my : 0u) | (obox ? 2u >> my : 0u);
+            myb = b;
+        }
+        if ((ldl & rdl) < 0 && (desc >> 29) == RT_CHILD_BOX) {
+            // this thread completed the root.  Q3: the reference leaves the root pair's parent undefined; defined as 0
+            uint32_t* nw = stage + myb * 16;
+            nw[3] = ((cc & 1u) ? 2u : 1u) << 29;
+            nw[11] = ((cc & 2u) ? 2u : 1u) << 29;
+        }
+    }
+    __syncthreads();
+    RT_STAMP(0, 2);
+
+    {
+        // the pairs completed here, 16 bytes per lane, four lanes per pair (sweeping in destination order instead -- whole
+        // 128-byte lines through an index -> boundary table -- measured the same: 467 vs 470 us at 10M).  A pair whose parent is completed at an upper
+        // level leaves with undefined w12 words (dwords 3 and 11); the upper-level kernel, which runs after this one,
+        // writes them -- as it writes every word of the pairs not completed here.
+        const uint4* st4 = reinterpret_cast<const uint4*>(stage);
+        uint4* dst = reinterpret_cast<uint4*>(a.nodes);
+#pragma unroll
+        for (uint32_t k = 0; k < 4 * C::CAP / NT; k++) {
+            const uint32_t c = tid + k * NT;          // 16-byte chunk of the pair that splits at boundary c / 4
+            const unsigned long long L = lock[c >> 2];
+            if ((c >> 2) < S && (uint32_t)L == kLockDone) store_stream(dst + (size_t)(uint32_t)(L >> 32) * 4 + (c & 3u), st4[c]);
+        }
+    }
+
+    RT_STAMP(0, 3);
+    // open roots = rendezvous points where only one child ever arrived, in boundary (= leaf) order
+    unsigned long long words[C::PER];
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < C::PER; j++) {
+        const uint32_t b = tid * C::PER + j;
+        const unsigned long long L = (b <= S) ? lock[b] : kLock64Empty;
+        words[j] = L;
+        mine += ((uint32_t)L < kLockDone) ? 1u : 0u;
+    }
+    uint32_t total;
+    uint32_t pos = block_excl_scan_u32<NT>(mine, ws, &total);
+#pragma unroll
+    for (uint32_t j = 0; j < C::PER; j++) {
+        const uint32_t rg = (uint32_t)words[j];
+        if (rg < kLockDone) {
+            if (pos < kMaxOpen) {
+                const uint32_t b = tid * C::PER + j;
+                const uint32_t osf = rg & 0x1FFu, osl = (rg >> 9) & 0x1FFu;
+                const uint32_t* h = stage + b * 16 + (osl + 1 == b ? 0u : 8u);   // a left child waits at its right end
+                uint4* o = reinterpret_cast<uint4*>(out_rec + (size_t)pos * kRecDwords);
+                store_sc1(o + 0, B0 + osf, B0 + osl, h[7], (rg >> 18) & 3u);
+                store_sc1(o + 1, h[0], h[1], h[2], h[4]);
+                store_sc1(o + 2, h[5], h[6], (uint32_t)dl[osf], (uint32_t)dl[osl + 1]);
+            }
+            pos++;
+        }
+    }
+    if (tid == 0) {
+        store_sc1(out_cnt, min(total, kMaxOpen));
+        if (total > kMaxOpen) atomicOr(a.status, kErrOpenOverflow);  // cannot happen: <= 2 * depth(62) open roots
+    }
+    RT_STAMP(0, 4);
 }
 
 // prefix table of the open-root counts of `nb` (<= 64) source blocks -> pref[0..64] in LDS; returns their sum
@@ -768,14 +943,14 @@ __device__ __forceinline__ void table_pass(const LevelArgs& a, uint32_t* smem, u
 }
 
 // ---- level 0: one 512-thread workgroup per 512 leaves (grids are sized for the largest possible n)
-__global__ __launch_bounds__(kLeafThreads, 6) void lbvh_leaf_kernel(LevelArgs a)   // three workgroups per CU (LDS), 24 waves
+__global__ __launch_bounds__(kLeafThreads, 4) void lbvh_leaf_kernel(LevelArgs a)   // four workgroups per CU: 32 waves
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t n = a.n_dev ? *a.n_dev : a.n;
     const uint32_t blk = blockIdx.x;
     const uint32_t B0 = blk * kLeafCap;
     const uint32_t S = B0 < n ? min(kLeafCap, n - B0) : 0u;
-    level_pass<true>(a, smem, n, B0, S, nullptr, a.cnt[0] + blk, a.rec[0] + (size_t)blk * kMaxOpen * kRecDwords);
+    leaf_pass(a, smem, n, B0, S, a.cnt[0] + blk, a.rec[0] + (size_t)blk * kMaxOpen * kRecDwords);
 }
 
 // ---- all upper levels in one launch: one workgroup per level-1 block; the workgroup that completes the inputs of a
@@ -833,7 +1008,7 @@ __global__ __launch_bounds__(1024) void lbvh_upper_kernel(LevelArgs a)
                 else table_pass<false, TableBig>(a, smem, n, S, src_rec, out_cnt, out_rec, so);
             }
         } else if (S <= RT_LBVH_FAST_CAP) {
-            level_pass<false>(a, smem, n, 0, S, src_rec, out_cnt, out_rec, 2 + (lvl - 1) * 7);
+            level_pass(a, smem, n, S, src_rec, out_cnt, out_rec, 2 + (lvl - 1) * 7);
         } else {
             // more open roots than one pass holds (deep trees: long runs of equal codes): kSubFan source blocks at a
             // time (always fit: kSubFan * kMaxOpen <= CAP) into this block's scratch, then one pass over those results
@@ -844,7 +1019,7 @@ __global__ __launch_bounds__(1024) void lbvh_upper_kernel(LevelArgs a)
                 const uint32_t sfirst = j * kSubFan;
                 const uint32_t snb = sfirst < nb ? min(kSubFan, nb - sfirst) : 0u;
                 const uint32_t SS = load_prefix(smem, src_cnt + sfirst, snb);
-                level_pass<false>(a, smem, n, 0, SS, src_rec + (size_t)sfirst * kMaxOpen * kRecDwords, sc + j,
+                level_pass(a, smem, n, SS, src_rec + (size_t)sfirst * kMaxOpen * kRecDwords, sc + j,
                                   sr + (size_t)j * kMaxOpen * kRecDwords);
             }
             // this workgroup's own stores, read back by its other waves: drain, make them visible, meet
@@ -853,7 +1028,7 @@ __global__ __launch_bounds__(1024) void lbvh_upper_kernel(LevelArgs a)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             const uint32_t S2 = load_prefix(smem, sc, kSubs);
-            level_pass<false>(a, smem, n, 0, S2, sr, out_cnt, out_rec);
+            level_pass(a, smem, n, S2, sr, out_cnt, out_rec);
         }
     }
 }

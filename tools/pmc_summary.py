@@ -13,4 +13,4 @@ for f in glob.glob(root + "/**/*_kernel_trace.csv", recursive=True):
 for k in agg:
     print(k, "calls(pmc rows)", max(len(v) for v in agg[k].values()), "dur_us mean", sum(dur[k]) / max(len(dur[k]), 1))
     for c, v in sorted(agg[k].items()):
-        print(f"   {c:32s} mean {sum(v)/len(v):16.1f}  n={len(v)}")
+        print(f"   {c:32s} mean {sum(v)/len(v):16.1f}  median {sorted(v)[len(v)//2]:16.1f}  n={len(v)}")
