@@ -433,29 +433,34 @@ __device__ __forceinline__ void leaf_pass(const LevelArgs& a, uint32_t* smem, ui
     uint32_t* sink = stage;
     const uint32_t tid = threadIdx.x;
 
-    for (uint32_t b = tid; b <= S; b += NT) {
-        lock[b] = kLock64Empty;
-        dl[b] = delta_adjacent(a.codes, (int)B0 + (int)b - 1, n);
-    }
-    __syncthreads();
-    RT_STAMP(0, 1);
-
     static_assert(C::CAP == NT, "one leaf per thread");
     const uint32_t s0 = tid, i = B0 + s0;
     const bool act = s0 < S;
-    float bx[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    // The block's loads are issued back to back -- sorted index, then the triangle it names, then the codes for the deltas --
+    // and nothing waits for the deltas before the climb: one exposed round trip less per workgroup than deltas, barrier,
+    // index, triangle.
+    uint32_t sv = 0, src = 0;
+    float v[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     if (act) {
         // GenerateTriangles (BottomUpBuilder.cu:287-312) fused: gather the triangle, emit the 64-byte leaf in sorted order
         // (ids defined), keep its box in registers.
-        uint32_t sv = a.sorted_idx[i];
-        uint32_t src = sv & 0x7FFFFFFFu;
+        sv = a.sorted_idx[i];
+        src = sv & 0x7FFFFFFFu;
         // the gather address comes from memory: never past the triangle array (a quad leaf also reads triangle src + 1)
         if (src + (sv >> 31) >= a.n) {
             atomicOr(a.status, kErrSortedIndex);
             sv = src = 0u;
         }
-        float v[9];
         load_tri9(a.tris + (size_t)src * 9, v);   // 36 bytes at a 4-byte-aligned address: 2 x 16-byte loads + 1 dword
+    }
+    for (uint32_t b = tid; b <= S; b += NT) {
+        lock[b] = kLock64Empty;
+        dl[b] = delta_adjacent(a.codes, (int)B0 + (int)b - 1, n);
+    }
+    RT_STAMP(0, 1);
+
+    float bx[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (act) {
         // the leaf goes to LDS first (the staging area is free until the climb starts) and leaves in the sweep below
         uint4* out = reinterpret_cast<uint4*>(stage + s0 * 16);
         float v3[3] = {v[6], v[7], v[8]};
@@ -501,6 +506,7 @@ __device__ __forceinline__ void leaf_pass(const LevelArgs& a, uint32_t* smem, ui
         // during the NEXT kernel that streams (scene_aabb of the following build: 100 -> 60 us at 10M).  nt on the strided
         // per-thread stores was the opposite: 838 us (profiles/r03_leaf_store_experiments.txt).
         __syncthreads();
+        RT_STAMP(0, 5);
         const uint4* st4 = reinterpret_cast<const uint4*>(stage);
         uint4* dst = reinterpret_cast<uint4*>(a.leaves + B0);
 #pragma unroll
@@ -509,6 +515,7 @@ __device__ __forceinline__ void leaf_pass(const LevelArgs& a, uint32_t* smem, ui
             if ((c >> 2) < S) store_stream(dst + c, st4[c]);
         }
         __syncthreads();   // the climb reuses the staging area
+        RT_STAMP(0, 6);
     }
     if (act) {
         uint32_t sf = s0, sl = s0, cc = 0, myb = 0;   // myb: the boundary my own node splits at (a box segment)

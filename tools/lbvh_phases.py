@@ -37,9 +37,12 @@ used = leaf[:, 0] > 0
 t = leaf[used]
 t0 = t[:, 0].min()
 print(f"n = {inp.num_triangles}; leaf kernel: {used.sum()} workgroups, first start -> last end {us(t[:, 4].max() - t0):.2f} us")
-names = ["init (deltas, locks)", "gather + leaf + climb", "node sweep", "open roots out"]
-for k, nm in enumerate(names):
-    d = us(t[:, k + 1] - t[:, k])
+# stamps: 0 start, 1 deltas + locks ready, 5 every gather landed (leaves in LDS), 6 leaf lines issued, 2 climb over,
+# 3 node sweep issued, 4 open roots out
+names = [("init (deltas, locks)", 0, 1), ("gather -> leaves in LDS", 1, 5), ("leaf lines out", 5, 6), ("climb", 6, 2),
+         ("node sweep", 2, 3), ("open roots out", 3, 4)]
+for nm, k0, k1 in names:
+    d = us(t[:, k1] - t[:, k0])
     print(f"  {nm:24s} avg {d.mean():7.2f}  min {d.min():7.2f}  max {d.max():7.2f} us")
 d = us(t[:, 4] - t[:, 0])
 print(f"  {'workgroup total':24s} avg {d.mean():7.2f}  min {d.min():7.2f}  max {d.max():7.2f} us")
