@@ -245,7 +245,7 @@ __global__ __launch_bounds__(NT, (NT == 512 && BITS == 8) ? 6 : 4) void sort_dow
                                                             uint32_t shift, uint32_t stride,
                                                             const uint32_t* __restrict__ offs,
                                                             const uint32_t* __restrict__ totals,
-                                                            const uint32_t* n_dev)
+                                                            const uint32_t* n_dev, uint32_t* exp_table = nullptr)
 {
     constexpr uint32_t RADIX = 1u << BITS;
     constexpr uint32_t NW = NT / 64;             // waves
@@ -398,6 +398,9 @@ __global__ __launch_bounds__(NT, (NT == 512 && BITS == 8) ? 6 : 4) void sort_dow
             uint32_t pos = gadj[__builtin_amdgcn_ubfe(kv.x, shift, BITS)] + j;
             if (EXP == 2) pos = tbase + j;        // linear stores instead of the scatter
             if (EXP == 1) pos = pos == 0xFFFFFFF3u ? 0u : 0x3FFFFFFFu;   // no stores (out of range: dropped)
+            if (EXP == 4)   // price of counting the NEXT pass's (digit, destination tile) histogram with one global atomic per key
+                __hip_atomic_fetch_add(exp_table + (size_t)__builtin_amdgcn_ubfe(kv.x, (shift + BITS) & 31u, BITS) * stride + (pos >> 12), 1u,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // (a position past the end -- impossible unless the tables in memory are corrupt -- is dropped by the
             // descriptor's range check: never a wild store)
             __builtin_amdgcn_raw_buffer_store_b32(kv.x, bk_out, pos * 4u, 0, 0);
@@ -462,6 +465,11 @@ static void radix_pass(const uint32_t* sk, const uint32_t* sv, uint32_t* dk, uin
     if (exper == 1) { RT_DS(512, false, 1); return; }
     if (exper == 2) { RT_DS(512, false, 2); return; }
     if (exper == 3) { RT_DS(512, false, 3); return; }
+    if (exper == 4) {
+        if (wide) sort_downsweep_kernel<BITS, 1024, false, 4><<<tiles, 1024, 0, st>>>(sk, sv, dk, dv, n, shift, stride, offs, dt, n_dev, hist);
+        else sort_downsweep_kernel<BITS, 512, false, 4><<<tiles, 512, 0, st>>>(sk, sv, dk, dv, n, shift, stride, offs, dt, n_dev, hist);
+        return;
+    }
 #endif
     if (wide) {
         if (ident) RT_DS(1024, true, 0); else RT_DS(1024, false, 0);
