@@ -195,6 +195,10 @@ __device__ __forceinline__ void box_step(const TraceParams& p, const Ray& r, Tra
 {
     const uint32_t cnt = t.cur >> 29;
     const uint4* np = reinterpret_cast<const uint4*>(p.nodes + (t.cur & kIndexMask));
+#ifdef RT_EXP_BOX_PAD   // experiment arm (csrc/Makefile librt_amd_exp.so): N extra VALU instructions per box step -- which pipe bounds the kernel?
+#pragma unroll
+    for (int q = 0; q < RT_EXP_BOX_PAD; q++) asm volatile("v_mov_b32 %0, %0" : "+v"(t.box_tests));
+#endif
     const bool two = cnt > 1;
     const int o1 = two ? 2 : 0;  // all four loads issue together; a lone slot is simply read twice
     const uint4 a0 = np[0], b0 = np[1], a1 = np[o1], b1 = np[o1 + 1];
