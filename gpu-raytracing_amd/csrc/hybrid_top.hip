@@ -11,7 +11,8 @@
 // stably -- the same rules as oracle/rt_oracle.c: ora_build_hybrid_top, so the two agree bit for bit.
 // One workgroup, one thread per sub-root position, everything in LDS; per level: classify tasks ->
 // bin (LDS integer atomics on the ordered-int encoding, order independent) -> select planes -> one
-// block scan for the stable partition, two for slot / queue allocation -> emit nodes and child tasks.
+// block scan for the stable partition, one (packed) for bin slots, node slots and queue positions -> emit nodes and
+// child tasks.  Inside the level loop the barriers order LDS only: the kernel reads back nothing it stores to memory.
 #include <mutex>
 
 #include "rt_device.hpp"
@@ -90,11 +91,21 @@ __global__ __launch_bounds__(256) void hybrid_top_kernel(rt_node* nodes, const i
     S.ids[0][tid] = tid;     // tmp_ids = 0, 1, 2, ... (BuildWrapper.cu:292-293,303)
     __syncthreads();
 
-    // root task: c_aabb = union of the sub-root BOXES (:341-346), p_aabb = the scene box (:324-326)
+    // root task: c_aabb = union of the sub-root BOXES (:341-346), p_aabb = the scene box (:324-326).  Min / max in the
+    // ordered-int encoding: wave reductions, then one LDS atomic per wave and plane (a serial loop of one thread per plane over
+    // 256 boxes was a sixth of this kernel's time)
+    int* rb = reinterpret_cast<int*>(&S.cc[0][0][0]);   // six words of level scratch nobody uses yet
+    if (tid < 6) rb[tid] = tid < 3 ? 0x7f7fffff : (int)0x80800000;   // ordered-int +FLT_MAX / -FLT_MAX
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const int v = tid < K ? float_to_ordered_int(S.box[tid][k]) : (k < 3 ? 0x7f7fffff : (int)0x80800000);
+        const int r = k < 3 ? wave_min_i32(v) : wave_max_i32(v);
+        if ((tid & 63u) == 0) { if (k < 3) atomicMin(&rb[k], r); else atomicMax(&rb[k], r); }
+    }
+    __syncthreads();
     if (tid < 6) {
-        float v = tid < 3 ? kFltMax : -kFltMax;
-        for (uint32_t i = 0; i < K; i++) v = tid < 3 ? fminf(v, S.box[i][tid]) : fmaxf(v, S.box[i][tid]);
-        S.tc[0][0][tid] = v;
+        S.tc[0][0][tid] = ordered_int_to_float(rb[tid]);
         S.tp[0][0][tid] = ordered_int_to_float(aabb_ordered[tid]);
     }
     if (tid == 0) {
@@ -140,14 +151,22 @@ __global__ __launch_bounds__(256) void hybrid_top_kernel(rt_node* nodes, const i
             }
             S.kind[tid] = my_kind;
         }
-        uint32_t nsplit;
-        const uint32_t slot = block_excl_scan_u32<256>((tid < T && my_kind == 1) ? 1u : 0u, S.ws, &nsplit);
+        // one scan for three allocations, packed (a task that splits -- binned or by the median -- takes 2 node slots and 2
+        // queue entries whatever SelectPlane decides later; a leaf task takes its primitive count): bin slot : 8 | node slots
+        // : 12 | queue entries : 12
+        const bool splits = tid < T && my_count > 2;
+        const uint32_t need = tid < T ? (splits ? 2u : (my_count == 1 ? 0u : my_count)) : 0u;
+        uint32_t packed_total;
+        const uint32_t packed = block_excl_scan_lds<256>(((tid < T && my_kind == 1) ? 1u : 0u) | (need << 8) | ((splits ? 2u : 0u) << 20),
+                                                         S.ws, &packed_total);
+        const uint32_t nsplit = packed_total & 0xFFu, total_need = (packed_total >> 8) & 0xFFFu, total_children = packed_total >> 20;
+        const uint32_t slot = packed & 0xFFu, alloc = (packed >> 8) & 0xFFFu, qpos = packed >> 20;
         if (tid < T) S.binslot[tid] = (int)slot;
         for (uint32_t e = tid; e < nsplit * 8 * 13; e += 256) {
             const uint32_t f = e % 13;
             (&S.bins[0][0][0])[e] = f == 12 ? 0 : ((f % 6) < 3 ? 0x7f7fffff : (int)0x80800000);   // ordered-int empty
         }
-        __syncthreads();
+        lds_barrier();
         // ---- B: every position finds its task (tasks are in increasing start order) and bins its primitive
         int mytask = -1;
         {
@@ -176,7 +195,7 @@ __global__ __launch_bounds__(256) void hybrid_top_kernel(rt_node* nodes, const i
             }
             atomicAdd(&B[12], 1);
         }
-        __syncthreads();
+        lds_barrier();
         // ---- C: one thread per splitting task: SelectPlane (:297-350) or the median split
         if (tid < T && my_kind != 0) {
             const uint32_t s = S.tstart[q][tid], e = S.tend[q][tid];
@@ -244,7 +263,7 @@ __global__ __launch_bounds__(256) void hybrid_top_kernel(rt_node* nodes, const i
                     for (int k = 0; k < 6; k++) { S.cp[tid][h][k] = cp[h][k]; S.cc[tid][h][k] = cc[h][k]; }
             }
         }
-        __syncthreads();
+        lds_barrier();
         // ---- D: stable partition of the ids (PartitionIds :352-380, made stable) via one block scan
         bool left = false;
         if (mytask >= 0) {
@@ -252,10 +271,10 @@ __global__ __launch_bounds__(256) void hybrid_top_kernel(rt_node* nodes, const i
             left = kd == 1 ? (S.binof[tid] <= S.plane[mytask]) : (kd == 2 ? tid < S.mid[mytask] : false);
         }
         uint32_t total_left;
-        const uint32_t lx = block_excl_scan_u32<256>(left ? 1u : 0u, S.ws, &total_left);
+        const uint32_t lx = block_excl_scan_lds<256>(left ? 1u : 0u, S.ws, &total_left);
         S.lex[tid] = lx;
         if (tid == 0) S.lex[kTopMax] = total_left;
-        __syncthreads();
+        lds_barrier();
         const int nq = q ^ 1;
         if (mytask >= 0 && S.kind[mytask] != 0) {
             const uint32_t s = S.tstart[q][mytask], e = S.tend[q][mytask];
@@ -265,10 +284,6 @@ __global__ __launch_bounds__(256) void hybrid_top_kernel(rt_node* nodes, const i
         }
         // ---- E: slot and queue allocation in task order, then emit nodes and child tasks (:396-464, :544-606)
         const int kd = tid < T ? S.kind[tid] : 0;
-        const uint32_t need = tid < T ? (kd == 0 ? (my_count == 1 ? 0u : my_count) : 2u) : 0u;
-        uint32_t total_need, total_children;
-        const uint32_t alloc = block_excl_scan_u32<256>(need, S.ws, &total_need);
-        const uint32_t qpos = block_excl_scan_u32<256>((tid < T && kd != 0) ? 2u : 0u, S.ws, &total_children);
         const uint32_t wi = S.write_index;
         if (tid < T) {
             const uint32_t s = S.tstart[q][tid], e = S.tend[q][tid], parent = S.tparent[q][tid];
@@ -292,12 +307,12 @@ __global__ __launch_bounds__(256) void hybrid_top_kernel(rt_node* nodes, const i
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (tid == 0) {
             S.write_index = wi + total_need;
             S.num_tasks = total_children;
         }
-        __syncthreads();
+        lds_barrier();
         q = nq;
     }
 }

@@ -27,32 +27,6 @@
 
 namespace rt {
 
-// workgroup barrier that orders LDS traffic only: outstanding global loads (the tile's keys, issued first) stay in flight
-// across it.  __syncthreads() would drain them (it is a fence for global memory too).
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// block_excl_scan_u32 with LDS-only barriers
-template <int NT>
-__device__ __forceinline__ uint32_t block_excl_scan_lds(uint32_t v, uint32_t* ws, uint32_t* total)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int NW = NT / 64;
-    const uint32_t incl = wave_incl_scan_u32(v);
-    if (lane == 63) ws[wave] = incl;
-    lds_barrier();
-    if (wave == 0) {
-        const uint32_t w = lane < NW ? ws[lane] : 0u;
-        const uint32_t wi = wave_incl_scan_u32(w);
-        if (lane < NW) ws[lane] = wi - w;
-        if (lane == NW - 1) ws[NW] = wi;
-    }
-    lds_barrier();
-    const uint32_t r = ws[wave] + incl - v;
-    *total = ws[NW];
-    lds_barrier();
-    return r;
-}
-
 // lanes (among the valid ones) whose BITS-bit digit equals mine, as two 32-bit halves.  Per bit: sign-extend the bit
 // (v_bfe_i32), one compare (the ballot), and per half one xnor + one and.
 template <uint32_t BITS>

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Runs N LBVH builds of the bench scene (for profiling): python3 tools/build_loop.py [N] [G] [grid|sorted]
+"""Runs N LBVH builds of the bench scene (for profiling): python3 tools/build_loop.py [N] [G] [grid|sorted|hybrid|pairs]
 
 `sorted`: the same triangles handed over in the order of their Morton codes (one build first, its leaves become the input):
 same codes, same tree shape, but the leaf kernel's gather walks the input front to back -- the bench mesh's random heights
-scatter the gather over the whole array.  The difference is the price of the gather's incoherence on this scene."""
+scatter the gather over the whole array.  The difference is the price of the gather's incoherence on this scene.
+`hybrid` / `pairs`: the --type hybrid and --pairs builds of the same mesh."""
 import importlib, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,8 +23,17 @@ if KIND == "sorted":
     leaves = inp.triangles_out[:64 * n].view(torch.float32).view(n, 16)
     tri = torch.cat([leaves[:, 0:3], leaves[:, 4:7], leaves[:, 8:11]], dim=1).cpu().numpy()
     inp = rt.BuildInput.allocate(tri)
+def build():
+    if KIND == "hybrid":
+        rt.RunBottomUpBuild(inp, hybrid=True)
+    elif KIND == "pairs":
+        rt.RunBottomUpBuild(inp, rt.Arguments(build_type=rt.kBottomUp, enable_pairs=True))
+    else:
+        rt.RunBottomUpBuild(inp)
+
+
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * N)]
 for i in range(N):
-    ev[2 * i].record(); rt.RunBottomUpBuild(inp); ev[2 * i + 1].record()
+    ev[2 * i].record(); build(); ev[2 * i + 1].record()
 torch.cuda.synchronize()
 print("build ms:", [round(ev[2 * i].elapsed_time(ev[2 * i + 1]), 4) for i in range(N)], "n =", inp.num_triangles)
