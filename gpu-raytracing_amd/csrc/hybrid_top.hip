@@ -38,7 +38,8 @@ struct TopSmem {
     uint32_t mid[kTopMax];
     float cc[kTopMax][2][6], cp[kTopMax][2][6];   // child centroid / primitive boxes
     int bins[kTopSplitMax][8][13];      // ordered-int p box [6], c box [6], count
-    int task_of[kTopMax], binof[kTopMax];
+    int binof[kTopMax];                 // bin of the primitive at a position
+    int child_q[kTopMax], child_m[kTopMax];   // per task that splits: first child's place in the next queue, first position of the right child
     uint32_t lex[kTopMax + 1];          // exclusive scan of the "goes left" flags
     uint32_t ws[16];
     uint32_t num_tasks, write_index;
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(256) void hybrid_top_kernel(rt_node* nodes, const i
     }
 
     int q = 0;  // current queue / ids buffer (alternates per level, like Task.buffer_idx)
+    int mytask = tid < K ? 0 : -1;   // the root task holds positions [0, K)
     while (true) {
         const uint32_t T = S.num_tasks;
         if (T == 0) break;
@@ -167,17 +169,8 @@ __global__ __launch_bounds__(256) void hybrid_top_kernel(rt_node* nodes, const i
             (&S.bins[0][0][0])[e] = f == 12 ? 0 : ((f % 6) < 3 ? 0x7f7fffff : (int)0x80800000);   // ordered-int empty
         }
         lds_barrier();
-        // ---- B: every position finds its task (tasks are in increasing start order) and bins its primitive
-        int mytask = -1;
-        {
-            int lo = 0, hi = (int)T - 1;
-            while (lo < hi) {                                      // largest t with tstart[t] <= tid
-                const int m = (lo + hi + 1) >> 1;
-                if (S.tstart[q][m] <= tid) lo = m; else hi = m - 1;
-            }
-            if (S.tstart[q][lo] <= tid && tid < S.tend[q][lo]) mytask = lo;
-        }
-        S.task_of[tid] = mytask;
+        // ---- B: every position bins its primitive (`mytask`: the task whose range holds position tid, carried from level to
+        // level -- a position of a task that split goes to one of its two children, see E)
         if (mytask >= 0 && S.kind[mytask] == 1) {
             const float* bx = S.box[S.ids[q][tid]];
             const int ax = S.axis[mytask];
@@ -298,6 +291,8 @@ __global__ __launch_bounds__(256) void hybrid_top_kernel(rt_node* nodes, const i
                 const uint32_t child_index = wi + alloc;
                 put_node(&nodes[parent], S.tp[q][tid], child_index, 2, RT_CHILD_BOX);
                 const uint32_t m = kd == 1 ? s + (S.lex[e] - S.lex[s]) : S.mid[tid];
+                S.child_q[tid] = (int)qpos;
+                S.child_m[tid] = (int)m;
                 for (int h = 0; h < 2; h++) {
                     const uint32_t o = qpos + h;
                     for (int k = 0; k < 6; k++) { S.tc[nq][o][k] = S.cc[tid][h][k]; S.tp[nq][o][k] = S.cp[tid][h][k]; }
@@ -312,6 +307,7 @@ __global__ __launch_bounds__(256) void hybrid_top_kernel(rt_node* nodes, const i
             S.write_index = wi + total_need;
             S.num_tasks = total_children;
         }
+        if (mytask >= 0) mytask = S.kind[mytask] == 0 ? -1 : S.child_q[mytask] + (tid >= (uint32_t)S.child_m[mytask] ? 1 : 0);
         lds_barrier();
         q = nq;
     }
