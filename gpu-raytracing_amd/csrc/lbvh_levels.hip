@@ -392,7 +392,7 @@ __device__ __forceinline__ void level_pass(const LevelArgs& a, uint32_t* smem, u
 }
 
 // ---- the leaf level's pass.  Same agglomeration as level_pass, laid out for occupancy: the leaf level is where the
-// bytes are (a gather of 40 bytes and 208 bytes of stores per leaf) and a workgroup alternates between memory phases and the
+// bytes are (44 bytes loaded and 128 bytes stored per leaf) and a workgroup alternates between memory phases and the
 // climb, so what hides the climb is other workgroups of the same CU.  LDS decides how many there are.  Here a segment's
 // waiting state IS its half of its parent's node pair: the node that splits at boundary b is staged at stage[b], the first
 // child to arrive writes its box and descriptor straight into its slot there and exchanges (range | cc | far delta, own
