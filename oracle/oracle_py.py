@@ -395,3 +395,26 @@ def ref_pack_node(mn, mx, parent: int, count: int, child: int, type_: int) -> np
     out = np.zeros(1, NODE)
     R.ref_pack_node(_p(np.asarray(mn, np.float32)), _p(np.asarray(mx, np.float32)), parent, count, child, type_, _p(out))
     return out
+
+
+# ---------------------------------------------------------------- Common.cuh's small host-callable arithmetic, both sides
+def box_helpers(which: str):
+    """(triangle_centre, triangle_box, box_centre, box_combine, box_intersection) of the oracle (`which` = "ora": the helpers
+    its build paths call) or of the reference's Common.cuh compiled from its tree (`which` = "ref").  Each takes / returns
+    float32 arrays; box_intersection returns (box, valid)."""
+    L = lib() if which == "ora" else ctypes.CDLL(os.path.join(_HERE, "_ref", "libref_pairing.so"))
+    pre = "ora_" if which == "ora" else "ref_"
+    vp = ctypes.c_void_p
+
+    def call(name, ins, nout, ret_int=False):
+        f = getattr(L, pre + name)
+        f.argtypes = [vp] * (len(ins) + 1)
+        f.restype = ctypes.c_int if ret_int else None
+        arrs = [np.ascontiguousarray(a, np.float32) for a in ins]
+        out = np.zeros(nout, np.float32)
+        r = f(*[_p(a) for a in arrs], _p(out))
+        return (out, bool(r)) if ret_int else out
+
+    return (lambda v9: call("triangle_centre", [v9], 3), lambda v9: call("triangle_box", [v9], 6),
+            lambda b6: call("box_centre", [b6], 3), lambda a6, b6: call("box_combine", [a6, b6], 6),
+            lambda a6, b6: call("box_intersection", [a6, b6], 6, ret_int=True))

@@ -66,4 +66,38 @@ void ref_pack_node(const float* mn, const float* mx, unsigned parent, unsigned c
     memcpy(out, &n, sizeof n);
 }
 
+// ---- Common.cuh's own __host__ __device__ arithmetic, called as the reference wrote it (no restatement): the tests hold
+// the oracle's helpers (ora_triangle_centre, ora_triangle_box, ora_box_centre, ora_box_combine, ora_box_intersection)
+// against these, bit for bit
+static Triangle tri_of(const float* v)
+{
+    return Triangle(make_float3(v[0], v[1], v[2]), make_float3(v[3], v[4], v[5]), make_float3(v[6], v[7], v[8]));
+}
+static AABB box_of(const float* b) { return AABB(make_float3(b[0], b[1], b[2]), make_float3(b[3], b[4], b[5])); }
+static void put_box(const AABB& a, float* o)
+{
+    o[0] = a.min.x; o[1] = a.min.y; o[2] = a.min.z; o[3] = a.max.x; o[4] = a.max.y; o[5] = a.max.z;
+}
+void ref_triangle_centre(const float* v, float* out)        // Triangle::Centre (Common.cuh:240-242)
+{
+    Triangle t = tri_of(v);
+    const float3 c = t.Centre();
+    out[0] = c.x; out[1] = c.y; out[2] = c.z;
+}
+void ref_triangle_box(const float* v, float* out) { put_box(AABB(tri_of(v)), out); }   // AABB(Triangle) (:263-267)
+void ref_box_centre(const float* b, float* out)             // AABB::Centre (:279)
+{
+    AABB a = box_of(b);
+    const float3 c = a.Centre();
+    out[0] = c.x; out[1] = c.y; out[2] = c.z;
+}
+void ref_box_combine(const float* a, const float* b, float* out) { put_box(Combine(box_of(a), box_of(b)), out); }   // (:299-305)
+int ref_box_intersection(const float* a, const float* b, float* out)   // AABB::Intersection + Valid (:269-277)
+{
+    AABB x = box_of(a);
+    AABB r = x.Intersection(box_of(b));
+    put_box(r, out);
+    return r.Valid() ? 1 : 0;
+}
+
 }  // extern "C"

@@ -38,6 +38,12 @@ static inline ora_f3 normalize3(ora_f3 v)
     float inv_len = 1.0f / sqrtf(dot3(v, v));
     return scale3(v, inv_len);
 }
+/* Triangle::Centre() (Common.cuh:240-242): (v0 + v1 + v2) / 3.0f, componentwise, left to right */
+static inline ora_f3 tri_centre(const ora_triangle* t)
+{
+    ora_f3 c = add3(add3(t->v0, t->v1), t->v2);
+    return f3(c.x / 3.0f, c.y / 3.0f, c.z / 3.0f);
+}
 static inline float clampf(float f, float a, float b) { return fmaxf(a, fminf(f, b)); } /* helper_math.h:1161 */
 
 /* ------------------------------------------------------------------ DeviceUtils.cuh:3-13 */
@@ -107,8 +113,7 @@ void ora_morton_codes(const ora_triangle* tris, uint32_t n, const int32_t aabb[6
     ora_f3 ext = sub3(smax, smin);
 #pragma omp parallel for num_threads(g_threads) schedule(static)
     for (int64_t i = 0; i < (int64_t)n; i++) {
-        ora_f3 c = add3(add3(tris[i].v0, tris[i].v1), tris[i].v2);
-        c = f3(c.x / 3.0f, c.y / 3.0f, c.z / 3.0f);
+        ora_f3 c = tri_centre(&tris[i]);
         c = div3(sub3(c, smin), ext);
         c = f3(clampf(c.x, 0.0f, 1.0f), clampf(c.y, 0.0f, 1.0f), clampf(c.z, 0.0f, 1.0f));
         codes[i] = morton3d(c.x, c.y, c.z);
@@ -415,10 +420,8 @@ uint32_t ora_build_pairs(const ora_triangle* tris, uint32_t n, ora_node* nodes, 
         const int second_valid = tid + 1 < n;
         const int merge = pair_merges(tris, n, tid);
         const ora_triangle *a = &tris[tid], *b = second_valid ? &tris[tid + 1] : &tris[tid];
-        ora_f3 centre = add3(add3(a->v0, a->v1), a->v2);
-        centre = f3(centre.x / 3.0f, centre.y / 3.0f, centre.z / 3.0f);
-        ora_f3 centre2 = add3(add3(b->v0, b->v1), b->v2);
-        centre2 = f3(centre2.x / 3.0f, centre2.y / 3.0f, centre2.z / 3.0f);
+        ora_f3 centre = tri_centre(a);
+        ora_f3 centre2 = tri_centre(b);
         if (merge) centre = scale3(add3(centre, centre2), 0.5f);
         ora_f3 c = div3(sub3(centre, smin), ext);
         c = f3(clampf(c.x, 0.0f, 1.0f), clampf(c.y, 0.0f, 1.0f), clampf(c.z, 0.0f, 1.0f));
@@ -1595,3 +1598,24 @@ float ora_rt_exp2f(float x) { return rt_exp2f(x); }
 double ora_rt_pow(double x, double y) { return rt_pow_d(x, y); }
 double ora_rt_log2(double x) { return rt_log2_pos(x); }
 double ora_rt_exp2(double x) { return rt_exp2_d(x); }
+
+/* ------------------------------------------------------------------ the small arithmetic the reference keeps in
+ * __host__ __device__ functions of Common.cuh, exported so that tests can hold the oracle's own helpers (the ones the
+ * build paths above call) against the reference's code compiled from its tree (oracle/ref_pairing_driver.cpp). */
+void ora_triangle_centre(const ora_triangle* t, float out[3])      /* Triangle::Centre, Common.cuh:240-242 */
+{
+    const ora_f3 c = tri_centre(t);
+    out[0] = c.x; out[1] = c.y; out[2] = c.z;
+}
+void ora_triangle_box(const ora_triangle* t, float out[6]) { tri_box(t, out); }   /* AABB(Triangle), Common.cuh:263-267 */
+void ora_box_centre(const float b[6], float out[3]) { box_centre(b, out); }       /* AABB::Centre, Common.cuh:279 */
+void ora_box_combine(const float a[6], const float b[6], float out[6])            /* Combine, Common.cuh:299-305 */
+{
+    for (int k = 0; k < 6; k++) out[k] = a[k];
+    box_grow(out, b);
+}
+int ora_box_intersection(const float a[6], const float b[6], float out[6])        /* AABB::Intersection + Valid, :269-277 */
+{
+    box_intersection(a, b, out);
+    return box_valid(out);
+}

@@ -178,6 +178,14 @@ void ora_generate_lod(const uint32_t* src, int32_t sx, int32_t sy, uint32_t* dst
 /* analysis aid: when set, ora_trace adds 1 to p[first slot] for every sibling pair a ray visits */
 void ora_set_visit_counts(uint32_t* p);
 
+/* the oracle's small box / centroid helpers (Common.cuh's __host__ __device__ functions), exported for the tests that pin
+ * them to the reference's compiled code */
+void ora_triangle_centre(const ora_triangle* t, float out[3]);
+void ora_triangle_box(const ora_triangle* t, float out[6]);
+void ora_box_centre(const float b[6], float out[3]);
+void ora_box_combine(const float a[6], const float b[6], float out[6]);
+int  ora_box_intersection(const float a[6], const float b[6], float out[6]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -360,3 +360,41 @@ def test_rt_math_against_libm(ora):
     assert np.max(np.abs(gp[m] - ep[m]) / ep[m]) < 5e-13
     assert L.ora_rt_pow(0.0, 8.0) == 0.0 and L.ora_rt_pow(0.0, 0.0) == 1.0 and L.ora_rt_pow(0.5, 0.0) == 1.0
     assert L.ora_rt_log2f(0.0) == -np.inf and np.isnan(L.ora_rt_log2f(-1.0)) and L.ora_rt_log2f(1e-45) == -149.0
+
+
+def test_box_and_centroid_helpers_match_the_reference_code(ora):
+    """The small arithmetic under the builders -- Triangle::Centre (the Morton codes' centroid), AABB(Triangle) (leaf boxes),
+    AABB::Centre (SAH bins), Combine, AABB::Intersection + Valid (spatial splits); Common.cuh:240-305 -- as the oracle's build
+    paths compute it, against the reference's own functions compiled from its tree (oracle/ref_pairing_driver.cpp), bit for
+    bit: random triangles over twelve orders of magnitude, degenerate (repeated vertices), tiny, huge and signed values.
+    (Inputs with both +0 and -0 in one comparison are left out: the host library's fminf / fmaxf pick by argument order there.)"""
+    if not ora.ref_pairing_available():
+        pytest.skip("oracle/_ref/libref_pairing.so is not built")
+    o_ctr, o_tbox, o_bctr, o_comb, o_isect = ora.box_helpers("ora")
+    r_ctr, r_tbox, r_bctr, r_comb, r_isect = ora.box_helpers("ref")
+    rng = np.random.default_rng(11)
+    bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
+    n_valid = 0
+    for trial in range(4000):
+        scale = np.float32(10.0) ** rng.integers(-6, 7)
+        t = (rng.standard_normal(9) * scale).astype(np.float32)
+        if trial % 9 == 0:
+            t[3:6] = t[0:3]                                   # repeated vertex
+        if trial % 13 == 0:
+            t[rng.integers(0, 9)] = np.float32(3.0e38) * rng.choice([-1, 1])
+        if trial % 17 == 0:
+            t[rng.integers(0, 9)] = np.float32(1.0e-42)       # denormal
+        assert (bits(o_ctr(t)) == bits(r_ctr(t))).all(), trial
+        tb = o_tbox(t)
+        assert (bits(tb) == bits(r_tbox(t))).all(), trial
+        assert (bits(o_bctr(tb)) == bits(r_bctr(tb))).all(), trial
+        u = (rng.standard_normal(9) * scale).astype(np.float32)
+        ub = o_tbox(u)
+        assert (bits(o_comb(tb, ub)) == bits(r_comb(tb, ub))).all(), trial
+        cell = np.concatenate([np.minimum(tb[:3], ub[:3]) + np.float32(0.25) * scale, np.maximum(tb[3:], ub[3:]) - np.float32(0.25) * scale])
+        if trial % 4 == 0:
+            cell = cell + np.float32(50.0) * scale            # a cell the triangle's box does not reach: Valid() is false
+        (ob, ov), (rb, rv) = o_isect(tb, cell.astype(np.float32)), r_isect(tb, cell.astype(np.float32))
+        assert ov == rv and (bits(ob) == bits(rb)).all(), trial
+        n_valid += int(ov)
+    assert 400 < n_valid < 3600     # both outcomes of Valid() were exercised
