@@ -485,12 +485,11 @@ __global__ __launch_bounds__(256) void sah_grid_kernel(const float* __restrict__
         else if (publish_gp) H->gp[threadIdx.x] = fold[threadIdx.x];
     }
     const uint32_t L = n_dev ? *n_dev : n;
-    __shared__ int cp[kSahCells][6], cc[kSahCells][6];
+    // cw[cell]: primitive box [0, 6), centroid box [6, 12), the "max" words kept complemented (max x = ~min ~x on the ordered
+    // ints) so that all twelve updates are the same LDS instruction
+    __shared__ int cw[kSahCells][12];
     __shared__ uint32_t cnt[kSahCells];
-    for (uint32_t j = threadIdx.x; j < kSahCells * 6; j += 256) {
-        (&cp[0][0])[j] = (j % 6) < 3 ? kEmptyLo : kEmptyHi;
-        (&cc[0][0])[j] = (j % 6) < 3 ? kEmptyLo : kEmptyHi;
-    }
+    for (uint32_t j = threadIdx.x; j < kSahCells * 12; j += 256) (&cw[0][0])[j] = kEmptyLo;   // (~kEmptyHi == kEmptyLo)
     if (threadIdx.x < kSahCells) cnt[threadIdx.x] = 0;
     __syncthreads();
     float glo[3], ghi[3];
@@ -500,7 +499,7 @@ __global__ __launch_bounds__(256) void sah_grid_kernel(const float* __restrict__
     int cell = -1;
     int v[12];
 #pragma unroll
-    for (int k = 0; k < 12; k++) v[k] = (k % 6) < 3 ? kEmptyLo : kEmptyHi;
+    for (int k = 0; k < 12; k++) v[k] = kEmptyLo;
     if (i < L) {
         float b[6];
         load_box(aabbs, i, b);
@@ -517,8 +516,8 @@ __global__ __launch_bounds__(256) void sah_grid_kernel(const float* __restrict__
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             const int ctr = float_to_ordered_int((b[k] + b[3 + k]) * 0.5f);
-            v[k] = float_to_ordered_int(b[k]); v[3 + k] = float_to_ordered_int(b[3 + k]);
-            v[6 + k] = ctr; v[9 + k] = ctr;
+            v[k] = float_to_ordered_int(b[k]); v[3 + k] = ~float_to_ordered_int(b[3 + k]);
+            v[6 + k] = ctr; v[9 + k] = ~ctr;
         }
     }
     // consecutive leaves mostly share a cell: when the whole wave agrees, reduce in registers and touch LDS once
@@ -526,20 +525,29 @@ __global__ __launch_bounds__(256) void sah_grid_kernel(const float* __restrict__
     if (c0 >= 0 && __builtin_amdgcn_ballot_w64(cell == c0) == ~0ull) {
 #pragma unroll
         for (int k = 0; k < 12; k++) {
-            const int r = (k % 6) < 3 ? wave_min_i32(v[k]) : wave_max_i32(v[k]);
-            if ((threadIdx.x & 63) == 0) {
-                int* dst = k < 6 ? &cp[c0][k] : &cc[c0][k - 6];
-                if ((k % 6) < 3) atomicMin(dst, r); else atomicMax(dst, r);
-            }
+            const int r = wave_min_i32(v[k]);
+            if ((threadIdx.x & 63) == 0) atomicMin(&cw[c0][k], r);
         }
         if ((threadIdx.x & 63) == 0) atomicAdd(&cnt[c0], 64u);
     } else if (cell >= 0) {
+        // the wave's lanes fall into a handful of cells (on the bench mesh: four, by height): in a fixed word order every
+        // instruction would queue up to 64 lanes on those few words.  Lane i walks the twelve words starting at word i mod 12
+        // (the values rotated to match by a four-stage barrel shifter, as in sah_bin_kernel): the queues shrink 12x
+        const uint32_t r = threadIdx.x % 12u;
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            atomicMin(&cp[cell][k], v[k]);
-            atomicMax(&cp[cell][3 + k], v[3 + k]);
-            atomicMin(&cc[cell][k], v[6 + k]);
-            atomicMax(&cc[cell][3 + k], v[9 + k]);
+        for (int st = 0; st < 4; st++) {
+            const bool on = (r >> st) & 1u;
+            int t[12];
+#pragma unroll
+            for (int k = 0; k < 12; k++) t[k] = v[(k + (1 << st)) % 12];
+#pragma unroll
+            for (int k = 0; k < 12; k++) v[k] = on ? t[k] : v[k];
+        }
+        uint32_t w = r;
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            atomicMin(&cw[cell][w], v[k]);
+            w = w == 11u ? 0u : w + 1u;
         }
         atomicAdd(&cnt[cell], 1u);
     }
@@ -550,8 +558,8 @@ __global__ __launch_bounds__(256) void sah_grid_kernel(const float* __restrict__
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             int* g = &H->part_cell[blockIdx.x % kCellParts][c][0];
-            atomicMin(&g[k], cp[c][k]); atomicMax(&g[3 + k], cp[c][3 + k]);
-            atomicMin(&g[6 + k], cc[c][k]); atomicMax(&g[9 + k], cc[c][3 + k]);
+            atomicMin(&g[k], cw[c][k]); atomicMax(&g[3 + k], ~cw[c][3 + k]);
+            atomicMin(&g[6 + k], cw[c][6 + k]); atomicMax(&g[9 + k], ~cw[c][9 + k]);
         }
     }
 }
