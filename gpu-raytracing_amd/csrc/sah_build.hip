@@ -1060,14 +1060,46 @@ constexpr uint32_t kSmallSegs = 22;   // sub-tasks with >= 3 items alive in one 
 // immediates (the item-major layout of round 2 cleared with `(j % 6) < 3 ? lo : hi` -- an integer modulo per store, ~200 of
 // the ~970 vector instructions a level cost; the kernel is bound by instruction issue, profiles/r03_sah_small_experiments.txt)
 struct SmallSmem {
-    int sbox[2][12][64];              // [buffer][p box 6, c box 6][first lane of the sub-task], ordered ints
+    int sbox[2][12][64];              // [buffer][p box 6, c box 6][first lane of the sub-task], ordered ints, "max" words complemented
     int bins[7][kSmallSegs * 8];      // [primitive box 6, count][sub-task * 8 + bin]
     uint32_t splane[64], snl[64], skind[64];
 };
 __device__ __forceinline__ void small_box_to_float(const int (*t)[64], uint32_t s, float* f)   // words 0..5 of column s
 {
 #pragma unroll
-    for (int k = 0; k < 6; k++) f[k] = ordered_int_to_float(t[k][s]);
+    for (int k = 0; k < 6; k++) f[k] = ordered_int_to_float(k < 3 ? t[k][s] : ~t[k][s]);
+}
+// One item's contribution to the boxes of column `col`: primitive box b, centroid box = its centre.  The "max" words are
+// kept complemented (max x = ~min ~x on the ordered ints), so all twelve updates are ds_min_i32, and lane i walks the words
+// starting at word r = i mod 12 (values rotated to match by a four-stage barrel shifter): the lanes of one sub-task, which
+// all update the same column, queue on twelve different words instead of one (the same-address LDS atomics of these
+// reductions were half of this kernel's LDS cycles: profiles/r03_sah_small_experiments.txt).
+__device__ __forceinline__ void small_box_update(int (*t)[64], uint32_t col, const float* b, uint32_t r)
+{
+    int val[12];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int ctr = float_to_ordered_int((b[k] + b[3 + k]) * 0.5f);
+        val[k] = float_to_ordered_int(b[k]);
+        val[3 + k] = ~float_to_ordered_int(b[3 + k]);
+        val[6 + k] = ctr;
+        val[9 + k] = ~ctr;
+    }
+#pragma unroll
+    for (int st = 0; st < 4; st++) {
+        const bool on = (r >> st) & 1u;
+        int u[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) u[k] = val[(k + (1 << st)) % 12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) val[k] = on ? u[k] : val[k];
+    }
+    uint32_t w = r;
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        atomicMin(&t[w][col], val[k]);
+        w = w == 11u ? 0u : w + 1u;
+    }
 }
 
 // LDS traffic between the lanes of ONE wave: its DS operations execute in order, so only the compiler has to be kept
@@ -1097,22 +1129,14 @@ __device__ __forceinline__ void sah_small_task(const SahArgs& a, SmallSmem& S, u
     uint32_t s = 0, e = cnt, parent = R.parent_idx;
     bool active = lane < cnt;
     uint32_t cur = 0;
+    const uint32_t rot = lane % 12u;
     // root boxes
 #pragma unroll
-    for (int w = 0; w < 12; w++) S.sbox[0][w][lane] = (w % 6) < 3 ? kEmptyLo : kEmptyHi;
+    for (int w = 0; w < 12; w++) S.sbox[0][w][lane] = kEmptyLo;   // (~kEmptyHi == kEmptyLo)
     wave_lds_sync();
-    if (active) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const int ctr = float_to_ordered_int((b[k] + b[3 + k]) * 0.5f);
-            atomicMin(&S.sbox[0][k][0], float_to_ordered_int(b[k]));
-            atomicMax(&S.sbox[0][3 + k][0], float_to_ordered_int(b[3 + k]));
-            atomicMin(&S.sbox[0][6 + k][0], ctr);
-            atomicMax(&S.sbox[0][9 + k][0], ctr);
-        }
-    }
+    if (active) small_box_update(S.sbox[0], 0u, b, rot);
     wave_lds_sync();
-    if ((R.flags & 4u) && lane < 6) S.sbox[0][6 + lane][0] = a.H->gc[lane];   // the top root's centroid bounds are the scene's
+    if ((R.flags & 4u) && lane < 6) S.sbox[0][6 + lane][0] = lane < 3 ? a.H->gc[lane] : ~a.H->gc[lane];   // the top root's centroid bounds are the scene's
     wave_lds_sync();
 
     while (__builtin_amdgcn_ballot_w64(active)) {
@@ -1144,10 +1168,10 @@ __device__ __forceinline__ void sah_small_task(const SahArgs& a, SmallSmem& S, u
             for (int w = 0; w < 7; w++) S.bins[w][j] = w < 3 ? kEmptyLo : (w < 6 ? kEmptyHi : 0);
         }
 #pragma unroll
-        for (int w = 0; w < 12; w++) S.sbox[nxt][w][lane] = (w % 6) < 3 ? kEmptyLo : kEmptyHi;
+        for (int w = 0; w < 12; w++) S.sbox[nxt][w][lane] = kEmptyLo;
         float c[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) c[k] = active ? ordered_int_to_float(S.sbox[cur][6 + k][s]) : 0.0f;
+        for (int k = 0; k < 6; k++) c[k] = active ? ordered_int_to_float(k < 3 ? S.sbox[cur][6 + k][s] : ~S.sbox[cur][6 + k][s]) : 0.0f;
         const bool binned = active && !(sah_sa(c) <= 0.0f);
         int bin = 0;
         if (binned) {
@@ -1247,14 +1271,7 @@ __device__ __forceinline__ void sah_small_task(const SahArgs& a, SmallSmem& S, u
                 left = lane < s + nl;
             }
             const uint32_t cs = left ? s : s + nl;
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const int ctr = float_to_ordered_int((b[k] + b[3 + k]) * 0.5f);
-                atomicMin(&S.sbox[nxt][k][cs], float_to_ordered_int(b[k]));
-                atomicMax(&S.sbox[nxt][3 + k][cs], float_to_ordered_int(b[3 + k]));
-                atomicMin(&S.sbox[nxt][6 + k][cs], ctr);
-                atomicMax(&S.sbox[nxt][9 + k][cs], ctr);
-            }
+            small_box_update(S.sbox[nxt], cs, b, rot);
         }
         // push every item to its new lane (a permutation inside each sub-task; inactive lanes keep theirs)
         idv = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest * 4), (int)idv);
