@@ -1129,7 +1129,7 @@ __device__ __forceinline__ void sah_small_task(const SahArgs& a, SmallSmem& S, u
     uint32_t s = 0, e = cnt, parent = R.parent_idx;
     bool active = lane < cnt;
     uint32_t cur = 0;
-    const uint32_t rot = lane % 12u;
+    const uint32_t rot = lane % 12u, rot6 = lane % 6u;
     // root boxes
 #pragma unroll
     for (int w = 0; w < 12; w++) S.sbox[0][w][lane] = kEmptyLo;   // (~kEmptyHi == kEmptyLo)
@@ -1165,7 +1165,7 @@ __device__ __forceinline__ void sah_small_task(const SahArgs& a, SmallSmem& S, u
         const uint64_t segmask = active ? (((e >= 64 ? ~0ull : ((1ull << e) - 1ull))) & ~((1ull << s) - 1ull)) : 0ull;
         for (uint32_t j = lane; j < nseg * 8; j += 64) {
 #pragma unroll
-            for (int w = 0; w < 7; w++) S.bins[w][j] = w < 3 ? kEmptyLo : (w < 6 ? kEmptyHi : 0);
+            for (int w = 0; w < 7; w++) S.bins[w][j] = w < 6 ? kEmptyLo : 0;   // (max words complemented: ~kEmptyHi == kEmptyLo)
         }
 #pragma unroll
         for (int w = 0; w < 12; w++) S.sbox[nxt][w][lane] = kEmptyLo;
@@ -1186,10 +1186,24 @@ __device__ __forceinline__ void sah_small_task(const SahArgs& a, SmallSmem& S, u
         wave_lds_sync();
         if (binned) {
             const uint32_t cell = seg * 8 + (uint32_t)bin;
+            // (as in small_box_update: "max" words complemented, lane i starts at word i mod 6)
+            int val[6];
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                atomicMin(&S.bins[k][cell], float_to_ordered_int(b[k]));
-                atomicMax(&S.bins[3 + k][cell], float_to_ordered_int(b[3 + k]));
+            for (int k = 0; k < 3; k++) { val[k] = float_to_ordered_int(b[k]); val[3 + k] = ~float_to_ordered_int(b[3 + k]); }
+#pragma unroll
+            for (int st = 0; st < 3; st++) {
+                const bool on = (rot6 >> st) & 1u;
+                int u[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) u[k] = val[(k + (1 << st)) % 6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) val[k] = on ? u[k] : val[k];
+            }
+            uint32_t w = rot6;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                atomicMin(&S.bins[w][cell], val[k]);
+                w = w == 5u ? 0u : w + 1u;
             }
             atomicAdd(&S.bins[6][cell], 1);     // items per bin (round 2: eight 64-bit ballot popcounts per level)
         }
@@ -1210,7 +1224,7 @@ __device__ __forceinline__ void sah_small_task(const SahArgs& a, SmallSmem& S, u
                 for (int i = 0; i < 7; i++) {
                     const uint32_t cell = seg * 8 + (uint32_t)(bwd ? 7 - i : i);
 #pragma unroll
-                    for (int k = 0; k < 6; k++) bw[i][k] = S.bins[k][cell];
+                    for (int k = 0; k < 6; k++) bw[i][k] = k < 3 ? S.bins[k][cell] : ~S.bins[k][cell];
                     bc[i] = (uint32_t)S.bins[6][cell];
                 }
                 int run[6] = {kEmptyLo, kEmptyLo, kEmptyLo, kEmptyHi, kEmptyHi, kEmptyHi};
