@@ -1059,12 +1059,15 @@ constexpr uint32_t kSmallSegs = 22;   // sub-tasks with >= 3 items alive in one 
 // Word-major LDS tables: the word index of every access is a compile-time constant, so clearing a table is a few stores of
 // immediates (the item-major layout of round 2 cleared with `(j % 6) < 3 ? lo : hi` -- an integer modulo per store, ~200 of
 // the ~970 vector instructions a level cost; the kernel is bound by instruction issue, profiles/r03_sah_small_experiments.txt)
+constexpr uint32_t kSmallCol = 65, kSmallBinRow = kSmallSegs * 8 + 1;   // 64 columns / 176 cells + 1
 struct SmallSmem {
-    int sbox[2][12][64];              // [buffer][p box 6, c box 6][first lane of the sub-task], ordered ints, "max" words complemented
-    int bins[7][kSmallSegs * 8];      // [primitive box 6, count][sub-task * 8 + bin]
+    // (row strides odd in banks: the twelve words of one column -- what the lanes of a sub-task update together, each starting
+    //  at a different word -- fall into twelve different banks; with strides of 64 and 176 dwords they shared one or two)
+    int sbox[2][12][kSmallCol];       // [buffer][p box 6, c box 6][first lane of the sub-task], ordered ints, "max" words complemented
+    int bins[7][kSmallBinRow];        // [primitive box 6, count][sub-task * 8 + bin]
     uint32_t splane[64], snl[64], skind[64];
 };
-__device__ __forceinline__ void small_box_to_float(const int (*t)[64], uint32_t s, float* f)   // words 0..5 of column s
+__device__ __forceinline__ void small_box_to_float(const int (*t)[kSmallCol], uint32_t s, float* f)   // words 0..5 of column s
 {
 #pragma unroll
     for (int k = 0; k < 6; k++) f[k] = ordered_int_to_float(k < 3 ? t[k][s] : ~t[k][s]);
@@ -1074,7 +1077,7 @@ __device__ __forceinline__ void small_box_to_float(const int (*t)[64], uint32_t 
 // starting at word r = i mod 12 (values rotated to match by a four-stage barrel shifter): the lanes of one sub-task, which
 // all update the same column, queue on twelve different words instead of one (the same-address LDS atomics of these
 // reductions were half of this kernel's LDS cycles: profiles/r03_sah_small_experiments.txt).
-__device__ __forceinline__ void small_box_update(int (*t)[64], uint32_t col, const float* b, uint32_t r)
+__device__ __forceinline__ void small_box_update(int (*t)[kSmallCol], uint32_t col, const float* b, uint32_t r)
 {
     int val[12];
 #pragma unroll
