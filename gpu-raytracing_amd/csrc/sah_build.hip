@@ -1065,7 +1065,7 @@ struct SmallSmem {
     //  at a different word -- fall into twelve different banks; with strides of 64 and 176 dwords they shared one or two)
     int sbox[2][12][kSmallCol];       // [buffer][p box 6, c box 6][first lane of the sub-task], ordered ints, "max" words complemented
     int bins[7][kSmallBinRow];        // [primitive box 6, count][sub-task * 8 + bin]
-    uint32_t splane[64], snl[64], skind[64];
+    uint32_t ssplit[64];              // per sub-task (at its first lane): kind : 2 | plane : 3 | items of the left child : 8
 };
 __device__ __forceinline__ void small_box_to_float(const int (*t)[kSmallCol], uint32_t s, float* f)   // words 0..5 of column s
 {
@@ -1114,7 +1114,9 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-constexpr uint32_t kSmallWaves = 4;   // independent waves per workgroup (single-wave workgroups are dispatch bound)
+constexpr uint32_t kSmallWaves = 2;   // independent waves per workgroup.  A wave's tables are 11.2 KB of LDS (9 granules of 1280 B):
+                                      // 2-wave workgroups fit 7 to a CU = 14 waves, 4-wave ones 3 = 12 (202 us), 7-wave ones 2 = 14
+                                      // but with the tail of the slowest of seven (208 us); 1 wave: 191 us, 2 waves: 189 us
 
 __device__ __forceinline__ void sah_small_task(const SahArgs& a, SmallSmem& S, uint32_t task, uint32_t lane)
 {
@@ -1266,7 +1268,7 @@ __device__ __forceinline__ void sah_small_task(const SahArgs& a, SmallSmem& S, u
                     }
                     if (pl >= 0) { kind = 1; plane = (uint32_t)pl; } else nl = count >> 1;
                 }
-                S.skind[s] = kind; S.splane[s] = plane; S.snl[s] = nl;
+                S.ssplit[s] = kind | (plane << 2) | (nl << 5);
                 // parent descriptor (SharedTaskBuilder.cu:544-558)
                 float pb[6];
                 small_box_to_float(S.sbox[cur], s, pb);
@@ -1277,7 +1279,7 @@ __device__ __forceinline__ void sah_small_task(const SahArgs& a, SmallSmem& S, u
         // ---- PartitionIds (:352-380), stable; child boxes; move the items
         uint32_t dest = lane;
         if (active) {
-            const uint32_t kind = S.skind[s], plane = S.splane[s], nl = S.snl[s];
+            const uint32_t sp = S.ssplit[s], kind = sp & 3u, plane = (sp >> 2) & 7u, nl = sp >> 5;
             bool left;
             if (kind == 1) {
                 left = (uint32_t)bin <= plane;
@@ -1295,7 +1297,7 @@ __device__ __forceinline__ void sah_small_task(const SahArgs& a, SmallSmem& S, u
 #pragma unroll
         for (int k = 0; k < 6; k++) b[k] = __int_as_float(__builtin_amdgcn_ds_permute((int)(dest * 4), __float_as_int(b[k])));
         if (active) {
-            const uint32_t nl = S.snl[s];
+            const uint32_t nl = S.ssplit[s] >> 5;
             const uint32_t child_index = (uint32_t)(bias + 2 * (int)(base + s + nl));
             if (lane < s + nl) { e = s + nl; parent = child_index; }
             else { s = s + nl; parent = child_index + 1; }
@@ -1462,7 +1464,7 @@ hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, boo
     // After each batch of levels the small-task kernel and the top-tree patch are launched at once (their counts live on the
     // device); only then does the host read the number of live tasks.  In the common case (the first batch finished every
     // task) that read is the build's final synchronisation and nothing waits for it.
-    constexpr uint32_t kSmallGrid = 8192;
+    constexpr uint32_t kSmallGrid = 32768 / kSmallWaves;
     uint32_t small_done = 0;
     while (true) {
         for (uint32_t i = 0; i < batch && lvl + 1 < kSahMaxLevels; i++, lvl++) {
