@@ -9,4 +9,6 @@ for V in base "$@"; do
     python3 tools/trace_exp.py --steps 40 --warmup 5 --no-cpu-baseline --no-extras --type $T > $O/bench_${V}_$T.json 2> $O/bench_${V}_$T.err || { tail -5 $O/bench_${V}_$T.err; exit 1; }
     python3 -c "import sys,json; d=json.loads(open('$O/bench_${V}_$T.json').read()); print('$V', '$T', 'inflight', d['value'], 'serial', d['serial_mrays'])"
   done
+  python3 tools/trace_exp.py --steps 40 --warmup 5 --no-cpu-baseline --no-extras --camera b > $O/bench_${V}_camb.json 2> $O/bench_${V}_camb.err || { tail -5 $O/bench_${V}_camb.err; exit 1; }
+  python3 -c "import sys,json; d=json.loads(open('$O/bench_${V}_camb.json').read()); print('$V', 'camera b', 'inflight', d['value'], 'serial', d['serial_mrays'])"
 done
