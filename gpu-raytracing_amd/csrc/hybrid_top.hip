@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void hybrid_top_kernel(rt_node* nodes, const i
         if (tid < T) S.binslot[tid] = (int)slot;
         for (uint32_t e = tid; e < nsplit * 8 * 13; e += 256) {
             const uint32_t f = e % 13;
-            (&S.bins[0][0][0])[e] = f == 12 ? 0 : ((f % 6) < 3 ? 0x7f7fffff : (int)0x80800000);   // ordered-int empty
+            (&S.bins[0][0][0])[e] = f == 12 ? 0 : 0x7f7fffff;   // ordered-int empty ("max" words are kept complemented: ~0x80800000)
         }
         lds_barrier();
         // ---- B: every position bins its primitive (`mytask`: the task whose range holds position tid, carried from level to
@@ -179,12 +179,31 @@ __global__ __launch_bounds__(256) void hybrid_top_kernel(rt_node* nodes, const i
             bin = min(max(bin, 0), 7);   // the reference prints "bin out of bounds" and abandons the build
             S.binof[tid] = bin;
             int* B = S.bins[S.binslot[mytask]][bin];
+            // the positions of one (task, bin) update the same twelve words: "max" words complemented so that every update is
+            // the same ds_min_i32, and thread i starts at word i mod 12 (values rotated to match, as in sah_build.hip)
+            int val[12];
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                atomicMin(&B[k], float_to_ordered_int(bx[k]));
-                atomicMax(&B[3 + k], float_to_ordered_int(bx[3 + k]));
-                atomicMin(&B[6 + k], float_to_ordered_int(centre[k]));
-                atomicMax(&B[9 + k], float_to_ordered_int(centre[k]));
+                val[k] = float_to_ordered_int(bx[k]);
+                val[3 + k] = ~float_to_ordered_int(bx[3 + k]);
+                val[6 + k] = float_to_ordered_int(centre[k]);
+                val[9 + k] = ~float_to_ordered_int(centre[k]);
+            }
+            const uint32_t r = tid % 12u;
+#pragma unroll
+            for (int st = 0; st < 4; st++) {
+                const bool on = (r >> st) & 1u;
+                int u[12];
+#pragma unroll
+                for (int k = 0; k < 12; k++) u[k] = val[(k + (1 << st)) % 12];
+#pragma unroll
+                for (int k = 0; k < 12; k++) val[k] = on ? u[k] : val[k];
+            }
+            uint32_t w = r;
+#pragma unroll
+            for (int k = 0; k < 12; k++) {
+                atomicMin(&B[w], val[k]);
+                w = w == 11u ? 0u : w + 1u;
             }
             atomicAdd(&B[12], 1);
         }
@@ -198,7 +217,10 @@ __global__ __launch_bounds__(256) void hybrid_top_kernel(rt_node* nodes, const i
                 uint32_t bn[8];
                 const int (*B)[13] = S.bins[S.binslot[tid]];
                 for (int b = 0; b < 8; b++) {
-                    for (int k = 0; k < 6; k++) { bp[b][k] = ordered_int_to_float(B[b][k]); bc[b][k] = ordered_int_to_float(B[b][6 + k]); }
+                    for (int k = 0; k < 6; k++) {
+                        bp[b][k] = ordered_int_to_float(k < 3 ? B[b][k] : ~B[b][k]);
+                        bc[b][k] = ordered_int_to_float(k < 3 ? B[b][6 + k] : ~B[b][6 + k]);
+                    }
                     bn[b] = (uint32_t)B[b][12];
                 }
                 float lp[7][6], lc[7][6];
