@@ -141,7 +141,7 @@ struct Trav {
     {
         if (sp < kStackLds) lds[sp * 64] = e;
         else if (sp < kStackMax) spill[sp - kStackLds] = e;
-        sp = min(sp + 1, kStackMax);  // a 65th push is dropped (the reference overruns its array, Tracer.cu:353-369)
+        sp = min(sp + 1, kStackMax);  // a push onto a full stack is dropped (the reference overruns its array, Tracer.cu:353-369)
     }
     // A Box child (Tracer.cu:338-363), predicated on `in`: the first hit becomes `near`; a closer one (ties:
     // larger child index) displaces `near` onto the stack; otherwise it is pushed itself.  Bitwise logic on
@@ -155,14 +155,18 @@ struct Trav {
         near_d = take ? front : near_d;
     }
     // the current pair is finished: remaining slots of the same node (count > 2 only, never in an LBVH), else
-    // the nearest child (the reference pushes it last and pops it first), else a popped entry, else done
+    // the nearest child (the reference pushes it last and pops it first -- so on a FULL stack that push is dropped
+    // like any other and the entry below it is popped instead: same rule as the oracle), else a popped entry, else done
     __device__ __forceinline__ void advance()
     {
         const uint32_t cnt = cur >> 29;
         if (cnt > 2) { cur = ((cur & kIndexMask) + 2) | ((cnt - 2) << 29); return; }
-        if (near_e != kNoNear) { cur = near_e; near_e = kNoNear; near_d = __builtin_inff(); }
+        const bool keep = (near_e != kNoNear) & (sp < kStackMax);
+        if (keep) cur = near_e;
         else if (sp == 0) phase = PH_DONE;
         else { --sp; cur = sp < kStackLds ? lds[sp * 64] : spill[sp - kStackLds]; }
+        near_e = kNoNear;
+        near_d = __builtin_inff();
     }
     // second slot of the pair, evaluated with the CURRENT tmax (after any leaf hit of the first slot)
     __device__ __forceinline__ void second_slot(float tmin, float tmax)

@@ -66,6 +66,40 @@ def soup(n: int, seed: int = 7, dup_fraction: float = 0.25, size: float = 0.02) 
     return tris.reshape(n, 9)
 
 
+def fractal_corner(n: int, seed: int = 3, octaves: int = 59, top_exp: int = 42, size: float = 0.5) -> np.ndarray:
+    """A self-similar scene: n triangles whose distance from the origin corner is log-uniform over `octaves` octaves below
+    2^top_exp (radius = ldexp(1 + u, e): exact, libm-free), direction in the positive octant, edge length ~ size * radius.
+    Deep, skewed trees: the LBVH is a chain down the Morton bits and an index-bit tree below 2^(top_exp-10); the binned SAH
+    peels about three octaves per level.  A ray leaving the corner along the diagonal enters the nested ("rest") box
+    first at every level and defers the other child: oracle max_stack 26-29 (LBVH), 46-48 (SAH) with 59 octaves, and a
+    full 64-entry stack with 140 -- the traversal-stack tests (tests/test_gpu_traversal_edges.py)."""
+    idx = np.arange(n * 10, dtype=np.uint32)
+    h = pcg_hash(idx + np.uint32((seed * 0x01000193) & 0xFFFFFFFF)).reshape(n, 10)
+    r = (h >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
+    e = np.int32(top_exp) - (h[:, 9] % np.uint32(octaves)).astype(np.int32)
+    radius = np.ldexp(np.float32(1.0) + r[:, 0], e).astype(np.float32)
+    d = (np.float32(0.05) + r[:, 1:4] * np.float32(0.95)).astype(np.float32)
+    c = (d * radius[:, None]).astype(np.float32)
+    t = np.empty((n, 3, 3), np.float32)
+    t[:, 0] = c
+    t[:, 1] = c + (r[:, 4:7] - np.float32(0.5)) * (radius * np.float32(size))[:, None]
+    t[:, 2] = c + (r[:, 6:9] - np.float32(0.5)) * (radius * np.float32(size))[:, None]
+    return t.reshape(n, 9)
+
+
+def diagonal_camera(offset: float, max_depth: float) -> np.ndarray:
+    """Camera at (-offset, -offset, -offset) looking along (1, 1, 1) with a hand-written basis (w is NOT normalised: the
+    ray generator normalises p = ndc.x*u + ndc.y*v + w): with odd frame sizes the centre pixel has ndc = 0 and its ray
+    runs exactly down the diagonal through the origin."""
+    cam = np.zeros(1, dtype=CAMERA)
+    cam["position"] = np.float32(-offset)
+    cam["w"] = np.float32(1.0)
+    cam["u"] = np.array([1, -1, 0], np.float32) * np.float32(0.70710678)
+    cam["v"] = np.array([1, 1, -2], np.float32) * np.float32(0.40824829)
+    cam["scale"], cam["max_depth"] = np.float32(1.0), np.float32(max_depth)
+    return cam
+
+
 def flat_mesh(G: int, seed: int = 3) -> np.ndarray:
     """Grid with every y equal: the scene box is flat on y, (c-min)/(max-min) = 0/0 = NaN, clamp -> 1
     (SURVEY 'hard parts': the NaN clamp path of GenerateMortonCodes)."""
@@ -122,6 +156,11 @@ def flat_attributes(triangles: np.ndarray, material_ids=None) -> np.ndarray:
     normalize(cross(v1-v0, v2-v1)) on all three corners, uv = 0."""
     t = triangles.reshape(-1, 3, 3).astype(np.float32)
     e1, e2 = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1]
+    with np.errstate(over="ignore", invalid="ignore"):       # (huge or degenerate triangles: inf / NaN normals, as the loader would give)
+        return _flat_attributes(t, e1, e2, material_ids)
+
+
+def _flat_attributes(t, e1, e2, material_ids):
     c = np.stack([e1[:, 1] * e2[:, 2] - e1[:, 2] * e2[:, 1], e1[:, 2] * e2[:, 0] - e1[:, 0] * e2[:, 2],
                   e1[:, 0] * e2[:, 1] - e1[:, 1] * e2[:, 0]], axis=1).astype(np.float32)
     d = (c[:, 0] * c[:, 0] + c[:, 1] * c[:, 1] + c[:, 2] * c[:, 2]).astype(np.float32)

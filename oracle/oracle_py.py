@@ -198,7 +198,7 @@ def _texture_table(textures):
 
 def trace(leaves, nodes, root, count, camera, w, h, *, render_type=0, attributes=None, materials=None, light=(0, 0, 0),
           rows=None, spp=1, textures=None):
-    """TraceRays on the CPU.  Returns (rgba8 [h, w, 4] uint8, counters [box, tri, max_stack]).
+    """TraceRays on the CPU.  Returns (rgba8 [h, w, 4] uint8, counters [box, tri, max_stack, dropped_pushes]).
     textures: list of mip chains (see generate_lods) indexed by Material.texture / .bump / .disp."""
     L = lib()
     L.ora_set_textures.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
@@ -215,7 +215,7 @@ def trace(leaves, nodes, root, count, camera, w, h, *, render_type=0, attributes
 
 def _trace(leaves, nodes, root, count, camera, w, h, render_type, attributes, materials, light, rows, spp):
     rgba = np.zeros((h, w, 4), np.uint8)
-    counters = np.zeros(3, np.uint64)
+    counters = np.zeros(4, np.uint64)
     y0, y1 = (0, h) if rows is None else rows
     lt = np.asarray(light, np.float32)
     cam = np.ascontiguousarray(camera)

@@ -1082,7 +1082,7 @@ int ora_verify_hierarchy(const ora_node* nodes, uint32_t root, uint32_t count)
 /* ================================================================== Tracer.cu */
 typedef struct { ora_f3 origin; float tmin; ora_f3 direction; float tmax; } ray_t;       /* Tracer.cuh:9-14 */
 typedef struct { uint32_t primitive_id, tri_id; float bu, bv; } ray_result_t;            /* Tracer.cu:4-8   */
-typedef struct { uint32_t box_tests, tri_tests, max_stack; } stats_t;                    /* Tracer.cuh:4-7  */
+typedef struct { uint32_t box_tests, tri_tests, max_stack, dropped; } stats_t;           /* Tracer.cuh:4-7 (+ 2 test aids) */
 
 /* Tracer.cu:187-200 IntersectRayAabb */
 static inline int intersect_ray_aabb(const ora_node* node, const ray_t* ray, float* distance)
@@ -1134,12 +1134,14 @@ static inline int intersect_ray_triangle_pair(const ora_triangle_pair* tp, ray_t
     return hit_a || hit_b;
 }
 
-/* Tracer.cu:308-374 TraceRay.  The reference prints "stack overflow" when stack_size reaches 64 and
- * then writes out of bounds; here a push at 64 is dropped (cannot happen on a binary LBVH, SURVEY A). */
+/* Tracer.cu:308-374 TraceRay.  The reference prints "stack overflow" when stack_size reaches 64 and then writes
+ * out of bounds (undefined); here EVERY push onto a full stack -- the nearest child's final push included -- is
+ * dropped and counted in stats->dropped (cannot happen on a binary LBVH, SURVEY A; a SAH tree over a scene spanning
+ * 100+ octaves gets there, tests/test_gpu_traversal_edges.py).  trace_kernel.hip follows the same rule. */
 typedef struct { uint32_t index, count; } stack_entry_t;
 static uint32_t* g_visit_counts = 0;   /* analysis aid (tools/visit_histogram.py): per-slot visit counter, or NULL */
 void ora_set_visit_counts(uint32_t* p) { g_visit_counts = p; }
-#define PUSH(e) do { if (sp < 64) stack[sp++] = (e); if (sp > stats->max_stack) stats->max_stack = sp; } while (0)
+#define PUSH(e) do { if (sp < 64) stack[sp++] = (e); else stats->dropped++; if (sp > stats->max_stack) stats->max_stack = sp; } while (0)
 static int trace_ray(const ora_triangle_pair* leaves, const ora_node* nodes, uint32_t root, uint32_t count,
                      ray_t* ray, ray_result_t* rr, stats_t* stats)
 {
@@ -1437,7 +1439,7 @@ static ora_f3 ambient_shader255(const accel_t* as, const ray_t* ray, const ray_r
     if (use_shadows) {                                    /* (:447-462) */
         ray_t shadow;
         ray_result_t sres = {0, 0, 0.f, 0.f};
-        stats_t sstats = {0, 0, 0};
+        stats_t sstats = {0, 0, 0, 0};
         shadow.origin = hit_pos;
         shadow.direction = light_dir;
         shadow.tmin = 0.001f;
@@ -1472,12 +1474,13 @@ static ora_f3 shade_pixel(const ora_triangle_pair* leaves, const ora_node* nodes
     ray.tmin = 0.00001f;
     ray.tmax = max_depth;
     ray_result_t rr = {0, 0, 0.f, 0.f};
-    stats_t st = {0, 0, 0};
+    stats_t st = {0, 0, 0, 0};
     int hit = trace_ray(leaves, nodes, root, count, &ray, &rr, &st);
     float depth = hit ? ray.tmax : 0.0f;
     stats->box_tests += st.box_tests;
     stats->tri_tests += st.tri_tests;
     if (st.max_stack > stats->max_stack) stats->max_stack = st.max_stack;
+    stats->dropped += st.dropped;
 
     switch (render_type) {
     case ORA_DEPTH: {
@@ -1547,13 +1550,13 @@ int ora_trace(const ora_triangle_pair* leaves, const ora_node* nodes, uint32_t r
 {
     if (render_type < 0 || render_type > ORA_TEXTURE_LIT_SHADOWS) return -1;
     if (spp < 1) spp = 1;
-    uint64_t box = 0, tri = 0;
+    uint64_t box = 0, tri = 0, dropped = 0;
     uint32_t maxst = 0;
-#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 4) reduction(+ : box, tri) reduction(max : maxst)
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 4) reduction(+ : box, tri, dropped) reduction(max : maxst)
     for (int64_t yy = y0; yy < (int64_t)y1; yy++) {
         uint32_t y = (uint32_t)yy;
         for (uint32_t x = 0; x < w; x++) {
-            stats_t st = {0, 0, 0};
+            stats_t st = {0, 0, 0, 0};
             ora_f3 c;
             float alpha = 255.0f;
             if (spp == 1) {
@@ -1581,6 +1584,7 @@ int ora_trace(const ora_triangle_pair* leaves, const ora_node* nodes, uint32_t r
             px[3] = sat_u8(alpha);
             box += st.box_tests;
             tri += st.tri_tests;
+            dropped += st.dropped;
             if (st.max_stack > maxst) maxst = st.max_stack;
         }
     }
@@ -1588,6 +1592,7 @@ int ora_trace(const ora_triangle_pair* leaves, const ora_node* nodes, uint32_t r
         counters[0] += box;
         counters[1] += tri;
         if (maxst > counters[2]) counters[2] = maxst;
+        counters[3] += dropped;   /* pushes dropped on a full stack (primary rays) */
     }
     return 0;
 }

@@ -161,7 +161,8 @@ int  ora_verify_hierarchy(const ora_node* nodes, uint32_t root, uint32_t count);
 
 /* Tracer.cu:471-595 (TraceRays) over rows [y0,y1) of a w x h frame; rgba8 is the full frame (pitch 4w).
  * spp==1 is the reference; spp>1 is the SURVEY 8(d) config-5 extension.
- * counters (may be NULL): [0] += sum box_tests, [1] += sum tri_tests, [2] = max stack depth seen.
+ * counters (may be NULL, else FOUR words): [0] += sum box_tests, [1] += sum tri_tests, [2] = max stack depth seen
+ * (entries, the nearest child's push included), [3] += pushes dropped on a full 64-entry stack.
  * returns 0, or -1 for an unsupported render type. */
 int ora_trace(const ora_triangle_pair* leaves, const ora_node* nodes, uint32_t root, uint32_t count,
               const ora_attributes* attributes, const ora_material* materials, uint32_t num_materials,
