@@ -156,6 +156,9 @@ __global__ __launch_bounds__(256) void hybrid_top_kernel(rt_node* nodes, const i
         // one scan for three allocations, packed (a task that splits -- binned or by the median -- takes 2 node slots and 2
         // queue entries whatever SelectPlane decides later; a leaf task takes its primitive count): bin slot : 8 | node slots
         // : 12 | queue entries : 12
+        // (the fields cannot carry into each other: tasks that split hold >= 3 of the <= kTopMax primitives each, a level
+        // allocates at most 2 node slots / queue entries per task)
+        static_assert(kTopMax / 3 < (1 << 8) && 2 * kTopMax < (1 << 12), "packed scan: bin slot : 8 | node slots : 12 | queue entries : 12");
         const bool splits = tid < T && my_count > 2;
         const uint32_t need = tid < T ? (splits ? 2u : (my_count == 1 ? 0u : my_count)) : 0u;
         uint32_t packed_total;

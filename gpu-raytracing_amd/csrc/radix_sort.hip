@@ -458,6 +458,7 @@ hipError_t launch_radix_sort(uint32_t* keys, uint32_t* vals, uint32_t* tmp_keys,
                              bool ident0)
 {
     if (n == 0) return hipSuccess;
+    if (n > kSortMaxCount) return hipErrorInvalidValue;   // n * 4 would wrap the descriptors' 32-bit sizes
     const SortScratch L = sort_scratch_layout(n);
     char* base = static_cast<char*>(sort_scratch);
     uint32_t* digit_total = reinterpret_cast<uint32_t*>(base + L.digit_total);

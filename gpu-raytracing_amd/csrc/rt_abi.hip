@@ -95,6 +95,7 @@ int rt_radix_sort_u32_pairs(uint32_t* keys, uint32_t* values, uint32_t* tmp_keys
                             uint32_t count, void* sort_scratch, void* stream)
 {
     if (count && (!keys || !values || !tmp_keys || !tmp_values || !sort_scratch)) return RT_ERR_INVALID_ARGUMENT;
+    if (count > kSortMaxCount) return RT_ERR_TOO_LARGE;   // 32-bit byte offsets of the buffer descriptors (rt_abi.h)
     return hip_rc(launch_radix_sort(keys, values, tmp_keys, tmp_values, count, sort_scratch,
                                     static_cast<hipStream_t>(stream)));
 }
@@ -104,6 +105,7 @@ int rt_radix_sort_u32_pairs_bits(uint32_t* keys, uint32_t* values, uint32_t* tmp
 {
     if (count && (!keys || !values || !tmp_keys || !tmp_values || !sort_scratch)) return RT_ERR_INVALID_ARGUMENT;
     if (key_bits == 0 || key_bits > 32) return RT_ERR_INVALID_ARGUMENT;
+    if (count > kSortMaxCount) return RT_ERR_TOO_LARGE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     // an odd number of passes (3 x 10 bits) reads its input from the temporaries, an even one (4 x 8) from keys / values:
     // the result is in keys / values either way.  The input is moved only when it sits on the other side.

@@ -69,7 +69,10 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
                       __builtin_amdgcn_readlane(s, 32) + __builtin_amdgcn_readlane(s, 48));
 }
 // inclusive scan across the 64 lanes of a wave with DPP row shifts / row broadcasts: VALU only (a __shfl_up ladder goes
-// through the LDS crossbar: six dependent ds_bpermute round trips).  All 64 lanes must be active at the call.
+// through the LDS crossbar: six dependent ds_bpermute round trips).
+// CONTRACT: all 64 lanes must be active at the call (full EXEC: call it from wave-uniform control flow only) -- a DPP
+// source lane that is switched off contributes 0 / stale data, silently.  The __shfl_up ladder it replaced tolerated
+// partial waves; this does not.
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int /*lane*/ = 0)
 {
     int x = (int)v;
@@ -129,6 +132,9 @@ __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* ws
 
 // workgroup barrier that orders LDS traffic only: outstanding global loads (the tile's keys, issued first) stay in flight
 // across it.  __syncthreads() would drain them (it is a fence for global memory too).
+// CONTRACT: it orders LDS ONLY.  A value one wave STORES TO GLOBAL MEMORY before this barrier is not guaranteed visible to a
+// load of another wave after it (no vmcnt wait, no cache action): hand data across waves through LDS, or use
+// __syncthreads() / an explicit s_waitcnt vmcnt(0) for a global-memory hand-off.  Same for block_excl_scan_lds below.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // block_excl_scan_u32 with LDS-only barriers

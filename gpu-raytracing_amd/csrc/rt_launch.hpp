@@ -38,6 +38,9 @@ constexpr uint32_t kRadixBits = 8;
 constexpr uint32_t kRadix = 1u << kRadixBits;
 constexpr uint32_t kSortPasses = 4;
 constexpr uint32_t kRadixMax = 1024;   // the 10-bit passes of the Morton-key sort; tables are sized for it
+// The down-sweep addresses keys and values through buffer descriptors of n * 4 bytes with 32-bit byte offsets: n * 4 must
+// not wrap.  The builder stays far below (29-bit indices: n <= 2^28); the public sort entry points refuse larger counts.
+constexpr uint32_t kSortMaxCount = 0x3FFFFFFFu;
 
 inline uint32_t sort_num_tiles(uint32_t n) { return (n + kSortTile - 1) / kSortTile; }
 // the sort's tables hold one word per (digit, tile); a row is padded to a multiple of 4 words (one aligned 16-byte access

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 #include "MemoryBuffer.h"
 
@@ -19,7 +20,7 @@ static void NcclAssert(ncclResult_t r, const char* file, int line)
 
 void MultiGpuTracer::SetDevice(const Replica& r) const { check(hipSetDevice(r.device)); }
 
-MultiGpuTracer::MultiGpuTracer(int devices)
+MultiGpuTracer::MultiGpuTracer(int devices, int inflight)
 {
     int have = 0;
     check(hipGetDeviceCount(&have));
@@ -27,46 +28,73 @@ MultiGpuTracer::MultiGpuTracer(int devices)
         fprintf(stderr, "gpu_assert: --gpus %d but %d device(s) visible\n", devices, have);
         exit(2);
     }
+    if (inflight < 1 || inflight > 16) {
+        fprintf(stderr, "gpu_assert: --inflight %d (1 .. 16)\n", inflight);
+        exit(2);
+    }
     dev_.resize((size_t)devices);
     std::vector<int> list((size_t)devices);
-    for (int d = 0; d < devices; d++) {
-        Replica& r = dev_[(size_t)d];
-        r.device = list[(size_t)d] = d;
-        SetDevice(r);
-        check(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
-        check(hipEventCreate(&r.e0));
-        check(hipEventCreate(&r.e1));
-        check(hipMalloc((void**)&r.camera, sizeof(Camera)));
-        check(hipMalloc((void**)&r.num_tests, sizeof(uint64_t) * 4));
+    for (int d = 0; d < devices; d++) dev_[(size_t)d].device = list[(size_t)d] = d;
+    slot_.resize((size_t)inflight);
+    for (Slot& s : slot_) {
+        s.dev.resize((size_t)devices);
+        for (int d = 0; d < devices; d++) {
+            DevSlot& x = s.dev[(size_t)d];
+            SetDevice(dev_[(size_t)d]);
+            check(hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking));
+            check(hipEventCreate(&x.e0));
+            check(hipEventCreate(&x.e1));
+            check(hipMalloc((void**)&x.camera, sizeof(Camera)));
+            check(hipMalloc((void**)&x.num_tests, sizeof(uint64_t) * 4));
+        }
+        // one set of communicators per slot: RCCL orders the operations of a communicator, slots must stay independent
+        s.comms.resize((size_t)devices);
+        nccl_check(ncclCommInitAll(reinterpret_cast<ncclComm_t*>(s.comms.data()), devices, list.data()));
+        SetDevice(dev_[0]);
+        check(hipMalloc((void**)&s.totals, sizeof(uint64_t) * 4));
+        s.device_ms.assign((size_t)devices, 0.0f);
     }
-    comms_.resize((size_t)devices);
-    nccl_check(ncclCommInitAll(reinterpret_cast<ncclComm_t*>(comms_.data()), devices, list.data()));
-    SetDevice(dev_[0]);
-    check(hipMalloc((void**)&totals_, sizeof(uint64_t) * 4));
-    device_ms_.assign((size_t)devices, 0.0f);
+}
+
+void MultiGpuTracer::WaitAll()
+{
+    for (Slot& s : slot_)
+        for (size_t d = 0; d < dev_.size(); d++) {
+            SetDevice(dev_[d]);
+            check(hipStreamSynchronize(s.dev[d].stream));
+        }
 }
 
 MultiGpuTracer::~MultiGpuTracer()
 {
+    for (Slot& s : slot_)
+        for (size_t d = 0; d < dev_.size(); d++) {
+            (void)hipSetDevice(dev_[d].device);
+            (void)hipStreamSynchronize(s.dev[d].stream);
+        }
+    for (Slot& s : slot_) {
+        for (ncclComm* c : s.comms) if (c) (void)ncclCommDestroy(reinterpret_cast<ncclComm_t>(c));
+        for (size_t d = 0; d < dev_.size(); d++) {
+            DevSlot& x = s.dev[d];
+            (void)hipSetDevice(dev_[d].device);
+            for (void* p : {(void*)x.camera, (void*)x.frame, (void*)(d == 0 ? nullptr : x.compact), (void*)x.num_tests})
+                if (p) (void)hipFree(p);
+            if (x.e0) (void)hipEventDestroy(x.e0);
+            if (x.e1) (void)hipEventDestroy(x.e1);
+            if (x.stream) (void)hipStreamDestroy(x.stream);
+        }
+        (void)hipSetDevice(dev_[0].device);
+        if (s.staging) (void)hipFree(s.staging);
+        if (s.totals) (void)hipFree(s.totals);
+    }
     for (Replica& r : dev_) {
         (void)hipSetDevice(r.device);
-        (void)hipStreamSynchronize(r.stream);
-    }
-    for (ncclComm* c : comms_) if (c) (void)ncclCommDestroy(reinterpret_cast<ncclComm_t>(c));
-    for (size_t d = 0; d < dev_.size(); d++) {
-        Replica& r = dev_[d];
-        (void)hipSetDevice(r.device);
         r.textures.Free();
-        for (void* p : {(void*)r.in.triangles_in, (void*)r.in.triangles_out, (void*)r.in.nodes_out, r.in.scratch, (void*)r.camera,
-                        (void*)r.frame, (void*)(d == 0 ? nullptr : r.compact), (void*)r.num_tests, (void*)r.attributes, (void*)r.materials})
+        for (void* p : {(void*)r.in.triangles_in, (void*)r.in.triangles_out, (void*)r.in.nodes_out, r.in.scratch, (void*)r.attributes,
+                        (void*)r.materials})
             if (p) (void)hipFree(p);
-        if (r.e0) (void)hipEventDestroy(r.e0);
-        if (r.e1) (void)hipEventDestroy(r.e1);
-        if (r.stream) (void)hipStreamDestroy(r.stream);
     }
     (void)hipSetDevice(dev_.empty() ? 0 : dev_[0].device);
-    if (staging_) (void)hipFree(staging_);
-    if (totals_) (void)hipFree(totals_);
 }
 
 void MultiGpuTracer::UploadScene(const Scene& scene)
@@ -74,7 +102,9 @@ void MultiGpuTracer::UploadScene(const Scene& scene)
     const unsigned n = num_triangles_ = (unsigned)scene.triangles.size();
     std::vector<rt_material> mats;
     for (const Material& m : scene.library.materials) mats.push_back(m.pod());
-    for (Replica& r : dev_) {
+    for (size_t d = 0; d < dev_.size(); d++) {
+        Replica& r = dev_[d];
+        hipStream_t st = slot_[0].dev[d].stream;
         SetDevice(r);
         // the four build buffers of Display() frame 0 (main.cu:226-240); the scratch covers either builder
         const size_t bu = BuMemoryRequirements(n), sah = SahMemoryRequirements(n);
@@ -84,39 +114,49 @@ void MultiGpuTracer::UploadScene(const Scene& scene)
         check(hipMalloc(&r.in.scratch, bu > sah ? bu : sah));
         check(hipMalloc((void**)&r.in.nodes_out, rt_nodes_bytes(n)));
         if (n) {
-            check(hipMemcpyAsync(r.in.triangles_in, scene.triangles.data(), sizeof(Triangle) * n, hipMemcpyHostToDevice, r.stream));
+            check(hipMemcpyAsync(r.in.triangles_in, scene.triangles.data(), sizeof(Triangle) * n, hipMemcpyHostToDevice, st));
             check(hipMalloc((void**)&r.attributes, sizeof(Attributes) * n));
-            check(hipMemcpyAsync(r.attributes, scene.attributes.data(), sizeof(Attributes) * n, hipMemcpyHostToDevice, r.stream));
+            check(hipMemcpyAsync(r.attributes, scene.attributes.data(), sizeof(Attributes) * n, hipMemcpyHostToDevice, st));
         }
         r.num_materials = (uint32_t)mats.size();
         if (!mats.empty()) {
             check(hipMalloc((void**)&r.materials, sizeof(rt_material) * mats.size()));
-            check(hipMemcpyAsync(r.materials, mats.data(), sizeof(rt_material) * mats.size(), hipMemcpyHostToDevice, r.stream));
+            check(hipMemcpyAsync(r.materials, mats.data(), sizeof(rt_material) * mats.size(), hipMemcpyHostToDevice, st));
         }
         r.textures.Upload(scene.library);
         r.light = scene.light;
     }
-    for (Replica& r : dev_) { SetDevice(r); check(hipStreamSynchronize(r.stream)); }   // the host vectors may go away
+    WaitAll();   // the host vectors may go away
 }
 
 float MultiGpuTracer::Build(const Arguments& args)
 {
     sah_ = args.build_type == kSAH;
     const bool hybrid = args.build_type == kHybrid;
-    // the bottom-up build is a sequence of asynchronous launches: all devices build concurrently.  (RunSahBuild synchronises
-    // its stream -- data-dependent level count, like the reference -- so SAH replicas build one after the other.)
-    for (Replica& r : dev_) {
-        SetDevice(r);
-        check(hipEventRecord(r.e0, r.stream));
-        if (sah_) RunSahBuild(r.in, args, r.stream); else RunBottomUpBuild(r.in, args, hybrid, r.stream);
-        check(hipEventRecord(r.e1, r.stream));
+    // The bottom-up build is a sequence of asynchronous launches: one host thread issues it on every device and the devices
+    // build concurrently.  RunSahBuild reads a few words back per batch of levels (a data-dependent level count, as in the
+    // reference: BuildWrapper.cu:229) and so blocks its caller: each device's SAH build is issued by a thread of its own.
+    auto build_one = [&](size_t d) {
+        Replica& r = dev_[d];
+        DevSlot& x = slot_[0].dev[d];
+        check(hipSetDevice(r.device));
+        check(hipEventRecord(x.e0, x.stream));
+        if (sah_) RunSahBuild(r.in, args, x.stream); else RunBottomUpBuild(r.in, args, hybrid, x.stream);
+        check(hipEventRecord(x.e1, x.stream));
+    };
+    if (sah_ && dev_.size() > 1) {
+        std::vector<std::thread> th;
+        for (size_t d = 0; d < dev_.size(); d++) th.emplace_back(build_one, d);
+        for (std::thread& t : th) t.join();
+    } else {
+        for (size_t d = 0; d < dev_.size(); d++) build_one(d);
     }
     float worst = 0;
-    for (Replica& r : dev_) {
-        SetDevice(r);
-        check(hipEventSynchronize(r.e1));
+    for (size_t d = 0; d < dev_.size(); d++) {
+        SetDevice(dev_[d]);
+        check(hipEventSynchronize(slot_[0].dev[d].e1));
         float ms = 0;
-        check(hipEventElapsedTime(&ms, r.e0, r.e1));
+        check(hipEventElapsedTime(&ms, slot_[0].dev[d].e0, slot_[0].dev[d].e1));
         worst = ms > worst ? ms : worst;
     }
     return worst;
@@ -124,47 +164,84 @@ float MultiGpuTracer::Build(const Arguments& args)
 
 void MultiGpuTracer::Resize(int width, int height)
 {
+    WaitAll();
     width_ = width; height_ = height;
     const unsigned P = (unsigned)dev_.size();
     const size_t frame_bytes = (size_t)width * height * 4;
     const size_t compact_bytes = (size_t)CompactRows((unsigned)height, P) * width * 4;
-    SetDevice(dev_[0]);
-    if (staging_) check(hipFree(staging_));
-    check(hipMalloc((void**)&staging_, compact_bytes * P));
-    for (unsigned d = 0; d < P; d++) {
-        Replica& r = dev_[d];
-        SetDevice(r);
-        if (r.frame) check(hipFree(r.frame));
-        check(hipMalloc((void**)&r.frame, frame_bytes));
-        check(hipMemsetAsync(r.frame, 0, frame_bytes, r.stream));
-        if (d == 0) {
-            r.compact = staging_;      // device 0 renders its strips straight into slot 0 of the staging area
-        } else {
-            if (r.compact) check(hipFree(r.compact));
-            check(hipMalloc((void**)&r.compact, compact_bytes));
+    for (Slot& s : slot_) {
+        SetDevice(dev_[0]);
+        if (s.staging) check(hipFree(s.staging));
+        check(hipMalloc((void**)&s.staging, compact_bytes * P));
+        for (unsigned d = 0; d < P; d++) {
+            DevSlot& x = s.dev[d];
+            SetDevice(dev_[d]);
+            if (x.frame) check(hipFree(x.frame));
+            check(hipMalloc((void**)&x.frame, frame_bytes));
+            check(hipMemsetAsync(x.frame, 0, frame_bytes, x.stream));
+            if (d == 0) {
+                x.compact = s.staging;     // device 0 renders its strips straight into slot 0 of the staging area
+            } else {
+                if (x.compact) check(hipFree(x.compact));
+                check(hipMalloc((void**)&x.compact, compact_bytes));
+            }
         }
+        s.used = false;
     }
     decided_ = Partition::kAuto;
+    probe_slot_ = -1;
+    next_slot_ = last_slot_ = 0;
 }
 
-void MultiGpuTracer::TraceFrame(const Camera& camera, RenderType render_type, unsigned root, unsigned count, unsigned spp,
-                                Partition partition)
+// kAuto: the per-device times of the probe frame decide -- once they are there.  Never waits.
+void MultiGpuTracer::PollAutoDecision()
+{
+    if (decided_ != Partition::kAuto || probe_slot_ < 0) return;
+    Slot& s = slot_[(size_t)probe_slot_];
+    const unsigned P = (unsigned)dev_.size();
+    for (unsigned d = 0; d < P; d++) {
+        SetDevice(dev_[d]);
+        const hipError_t q = hipEventQuery(s.dev[d].e1);
+        if (q == hipErrorNotReady) return;
+        check(q);
+    }
+    std::vector<double> cost(P);
+    for (unsigned d = 0; d < P; d++) {
+        float ms = 0;
+        SetDevice(dev_[d]);
+        check(hipEventElapsedTime(&ms, s.dev[d].e0, s.dev[d].e1));
+        cost[d] = ms;
+    }
+    decided_ = ChoosePartition(cost.data(), P);
+    probe_slot_ = -1;
+}
+
+int MultiGpuTracer::TraceFrame(const Camera& camera, RenderType render_type, unsigned root, unsigned count, unsigned spp,
+                               Partition partition)
 {
     const unsigned P = (unsigned)dev_.size(), W = (unsigned)width_, H = (unsigned)height_;
     Partition use = partition;
-    if (partition == Partition::kAuto) use = decided_ == Partition::kAuto ? Partition::kBands : decided_;
-    if (P == 1 && partition == Partition::kAuto) use = Partition::kBands;   // (explicit strips on one device: the same code path, de-interleave = identity)
-    last_partition_ = use;
-    const size_t row = (size_t)W * 4;
-    const unsigned J = StripsPerDevice(H, P);
-    const size_t compact_bytes = (size_t)J * kStripRows * row;
+    if (partition == Partition::kAuto) {
+        if (P == 1) decided_ = Partition::kBands;   // (explicit strips on one device: the same code path, de-interleave = identity)
+        PollAutoDecision();
+        use = decided_ == Partition::kAuto ? Partition::kBands : decided_;
+    }
+    const int si = next_slot_;
+    next_slot_ = (next_slot_ + 1) % (int)slot_.size();
+    last_slot_ = si;
+    Slot& s = slot_[(size_t)si];
+    if (probe_slot_ == si) probe_slot_ = -1;          // the probe's events are about to be re-recorded
+    s.partition = use;
+    s.timed = false;
+    s.used = true;
 
     // ---- every device: camera (64 B, main.cu:151), counters, its part of the frame
     for (unsigned d = 0; d < P; d++) {
         Replica& r = dev_[d];
+        DevSlot& x = s.dev[d];
         SetDevice(r);
-        check(hipMemcpyAsync(r.camera, &camera, sizeof(Camera), hipMemcpyHostToDevice, r.stream));
-        check(hipMemsetAsync(r.num_tests, 0, sizeof(uint64_t) * 4, r.stream));
+        check(hipMemcpyAsync(x.camera, &camera, sizeof(Camera), hipMemcpyHostToDevice, x.stream));   // (pageable source: staged before the call returns)
+        check(hipMemsetAsync(x.num_tests, 0, sizeof(uint64_t) * 4, x.stream));
         DeviceSceneView view;
         view.attributes = r.attributes;
         view.materials = r.materials;
@@ -173,100 +250,87 @@ void MultiGpuTracer::TraceFrame(const Camera& camera, RenderType render_type, un
         view.textures = r.textures.table;
         view.num_textures = r.textures.count;
         view.light = r.light;
-        check(hipEventRecord(r.e0, r.stream));
+        check(hipEventRecord(x.e0, x.stream));
         if (use == Partition::kBands) {
             const RowBand b = BandOf(H, P, d);
             if (b.y1 > b.y0)
-                Trace(r.in.triangles_out, r.in.nodes_out, r.frame, width_, height_, r.camera, root, count, render_type, view,
-                      r.num_tests, b.y0, b.y1, spp, r.stream);
+                Trace(r.in.triangles_out, r.in.nodes_out, x.frame, width_, height_, x.camera, root, count, render_type, view,
+                      x.num_tests, b.y0, b.y1, spp, x.stream);
         } else if (StripsOwned(H, P, d)) {
-            TraceStrips(r.in.triangles_out, r.in.nodes_out, r.compact, width_, height_, r.camera, root, count, render_type, view,
-                        r.num_tests, kStripRows, d, P, spp, r.stream);
+            TraceStrips(r.in.triangles_out, r.in.nodes_out, x.compact, width_, height_, x.camera, root, count, render_type, view,
+                        x.num_tests, kStripRows, d, P, spp, x.stream);
         }
-        check(hipEventRecord(r.e1, r.stream));
+        check(hipEventRecord(x.e1, x.stream));
     }
-    timed_ = false;
+    if (partition == Partition::kAuto && decided_ == Partition::kAuto && probe_slot_ < 0) probe_slot_ = si;
 
-    // ---- the parts travel to device 0: ONE grouped send / recv per frame (point-to-point over xGMI into GPU 0), and the
-    // counters are summed on device 0 (ncclReduce runs on a 1-device communicator too)
+    // ---- the parts travel to device 0 (Partition.h GatherPlan): ONE grouped send / recv per frame (point-to-point over xGMI
+    // into GPU 0), and the counters are summed on device 0 (ncclReduce runs on a 1-device communicator too)
+    GatherOp ops[kMaxGatherOps];
+    const unsigned nops = GatherPlan(W, H, P, use, ops);
     nccl_check(ncclGroupStart());
     for (unsigned d = 0; d < P; d++) {
-        Replica& r = dev_[d];
-        ncclComm_t comm = reinterpret_cast<ncclComm_t>(comms_[d]);
-        nccl_check(ncclReduce(r.num_tests, d == 0 ? totals_ : r.num_tests, 4, ncclUint64, ncclSum, 0, comm, r.stream));
-        if (d == 0) continue;
-        ncclComm_t comm0 = reinterpret_cast<ncclComm_t>(comms_[0]);
-        if (use == Partition::kBands) {
-            const RowBand b = BandOf(H, P, d);
-            const size_t bytes = (size_t)(b.y1 - b.y0) * row;
-            if (!bytes) continue;
-            nccl_check(ncclSend(r.frame + b.y0 * row, bytes, ncclUint8, 0, comm, r.stream));
-            nccl_check(ncclRecv(dev_[0].frame + b.y0 * row, bytes, ncclUint8, (int)d, comm0, dev_[0].stream));
-        } else {
-            nccl_check(ncclSend(r.compact, compact_bytes, ncclUint8, 0, comm, r.stream));
-            nccl_check(ncclRecv(staging_ + d * compact_bytes, compact_bytes, ncclUint8, (int)d, comm0, dev_[0].stream));
-        }
+        DevSlot& x = s.dev[d];
+        nccl_check(ncclReduce(x.num_tests, d == 0 ? s.totals : x.num_tests, 4, ncclUint64, ncclSum, 0,
+                              reinterpret_cast<ncclComm_t>(s.comms[d]), x.stream));
+    }
+    ncclComm_t comm0 = reinterpret_cast<ncclComm_t>(s.comms[0]);
+    for (unsigned k = 0; k < nops; k++) {
+        const GatherOp& o = ops[k];
+        if (o.kind != GatherOp::kRecvBand && o.kind != GatherOp::kRecvCompact) continue;
+        DevSlot& x = s.dev[o.device];
+        const uint8_t* src = (o.kind == GatherOp::kRecvBand ? x.frame : x.compact) + o.src_off;
+        uint8_t* dst = (o.kind == GatherOp::kRecvBand ? s.dev[0].frame : s.staging) + o.dst_off;
+        nccl_check(ncclSend(src, o.bytes, ncclUint8, 0, reinterpret_cast<ncclComm_t>(s.comms[o.device]), x.stream));
+        nccl_check(ncclRecv(dst, o.bytes, ncclUint8, (int)o.device, comm0, s.dev[0].stream));
     }
     nccl_check(ncclGroupEnd());
 
-    if (use == Partition::kStrips) {
-        // de-interleave on device 0: local strip j of device d is global strip d + j*P -- one strided copy per source device
-        // for its strips that lie wholly inside the frame, one plain copy for a strip the frame's edge cuts
-        SetDevice(dev_[0]);
-        const size_t strip_bytes = kStripRows * row;
-        for (unsigned d = 0; d < P; d++) {
-            const unsigned owned = StripsOwned(H, P, d);
-            if (!owned) continue;
-            const unsigned last = d + (owned - 1) * P;
-            const bool cut = StripRowsInFrame(H, last) < kStripRows;
-            const unsigned whole = cut ? owned - 1 : owned;
-            const uint8_t* src = staging_ + d * compact_bytes;
-            if (whole)
-                check(hipMemcpy2DAsync(dev_[0].frame + (size_t)d * strip_bytes, (size_t)P * strip_bytes, src, strip_bytes, strip_bytes, whole,
-                                       hipMemcpyDeviceToDevice, dev_[0].stream));
-            if (cut)
-                check(hipMemcpyAsync(dev_[0].frame + (size_t)last * strip_bytes, src + (size_t)(owned - 1) * strip_bytes,
-                                     (size_t)StripRowsInFrame(H, last) * row, hipMemcpyDeviceToDevice, dev_[0].stream));
-        }
+    // ---- strips: de-interleave on device 0 (after the receives, on the same stream)
+    SetDevice(dev_[0]);
+    for (unsigned k = 0; k < nops; k++) {
+        const GatherOp& o = ops[k];
+        if (o.kind == GatherOp::kCopyStrips)
+            check(hipMemcpy2DAsync(s.dev[0].frame + o.dst_off, o.dst_pitch, s.staging + o.src_off, o.src_pitch, o.bytes, o.pieces,
+                                   hipMemcpyDeviceToDevice, s.dev[0].stream));
+        else if (o.kind == GatherOp::kCopyCut)
+            check(hipMemcpyAsync(s.dev[0].frame + o.dst_off, s.staging + o.src_off, o.bytes, hipMemcpyDeviceToDevice, s.dev[0].stream));
     }
-
-    if (partition == Partition::kAuto && decided_ == Partition::kAuto && P > 1) {
-        // the first frame went out as bands: its per-device times decide the partition of the following frames
-        const std::vector<float>& ms = DeviceMs();
-        std::vector<double> cost(ms.begin(), ms.end());
-        decided_ = ChoosePartition(cost.data(), P);
-    }
+    return si;
 }
 
-const std::vector<float>& MultiGpuTracer::DeviceMs()
+const std::vector<float>& MultiGpuTracer::DeviceMs(int slot)
 {
-    if (!timed_) {
+    Slot& s = slot_[(size_t)Resolve(slot)];
+    if (!s.timed && s.used) {
         for (size_t d = 0; d < dev_.size(); d++) {
             SetDevice(dev_[d]);
-            check(hipEventSynchronize(dev_[d].e1));
-            check(hipEventElapsedTime(&device_ms_[d], dev_[d].e0, dev_[d].e1));
+            check(hipEventSynchronize(s.dev[d].e1));
+            check(hipEventElapsedTime(&s.device_ms[d], s.dev[d].e0, s.dev[d].e1));
         }
-        timed_ = true;
+        s.timed = true;
     }
-    return device_ms_;
+    return s.device_ms;
 }
 
-const uint8_t* MultiGpuTracer::Frame()
+const uint8_t* MultiGpuTracer::Frame(int slot)
 {
-    for (Replica& r : dev_) { SetDevice(r); check(hipStreamSynchronize(r.stream)); }
+    Slot& s = slot_[(size_t)Resolve(slot)];
+    // every device's stream of this slot: the sends are on them (device 0's holds the receives and the de-interleave)
+    for (size_t d = 0; d < dev_.size(); d++) { SetDevice(dev_[d]); check(hipStreamSynchronize(s.dev[d].stream)); }
     SetDevice(dev_[0]);
-    return dev_[0].frame;
+    return s.dev[0].frame;
 }
 
-void MultiGpuTracer::FrameToHost(std::vector<uint8_t>& out)
+void MultiGpuTracer::FrameToHost(std::vector<uint8_t>& out, int slot)
 {
-    const uint8_t* f = Frame();
+    const uint8_t* f = Frame(slot);
     out.resize((size_t)width_ * height_ * 4);
     check(hipMemcpy(out.data(), f, out.size(), hipMemcpyDeviceToHost));
 }
 
-void MultiGpuTracer::Counters(uint64_t out[4])
+void MultiGpuTracer::Counters(uint64_t out[4], int slot)
 {
-    (void)Frame();
-    check(hipMemcpy(out, totals_, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost));
+    (void)Frame(slot);
+    check(hipMemcpy(out, slot_[(size_t)Resolve(slot)].totals, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost));
 }

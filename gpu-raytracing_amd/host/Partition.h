@@ -45,3 +45,48 @@ inline Partition ChoosePartition(const double* band_costs, unsigned devices, dou
     if (devices < 2 || mean <= 0.0) return Partition::kBands;
     return mx / mean > limit ? Partition::kStrips : Partition::kBands;
 }
+
+// ---- the gather of one frame on device 0, as data (host/MultiGpu.cpp executes exactly this plan; tests/test_host_mirror.py
+// replays it on the CPU for 1 - 8 devices and checks that every row of the frame is written exactly once, by its owner).
+//   bands : device d >= 1 sends rows [y0, y1) of its own full frame; device 0 receives them at the same rows of its frame
+//           (kRecvBand; device 0's own band is already in place).
+//   strips: device d >= 1 sends its whole compact buffer; device 0 receives it at staging slot d (kRecvCompact; device 0
+//           renders straight into slot 0); then per source device one strided copy staging -> frame for its strips that
+//           lie wholly inside the frame (kCopyStrips) and one plain copy for a strip the frame's edge cuts (kCopyCut).
+struct GatherOp {
+    enum Kind : unsigned { kRecvBand = 0, kRecvCompact = 1, kCopyStrips = 2, kCopyCut = 3 };
+    unsigned kind, device;            // the device whose pixels these are
+    uint64_t src_off;                 // kRecv*: byte offset in the SENDER's buffer (frame / compact); kCopy*: in device 0's staging
+    uint64_t dst_off;                 // kRecvBand, kCopy*: in device 0's frame; kRecvCompact: in device 0's staging
+    uint64_t bytes;                   // kRecv*, kCopyCut: contiguous bytes; kCopyStrips: bytes per piece
+    uint64_t src_pitch, dst_pitch;    // kCopyStrips: distance between pieces
+    unsigned pieces;                  // kCopyStrips: number of pieces (1 otherwise)
+};
+constexpr unsigned kMaxGatherOps = 3 * 64;
+// fills ops[<= 3 * devices]; returns their number.  compact_bytes = CompactRows(height, devices) * width * 4.
+inline unsigned GatherPlan(unsigned width, unsigned height, unsigned devices, Partition part, GatherOp* ops)
+{
+    const uint64_t row = (uint64_t)width * 4, strip_bytes = kStripRows * row;
+    const uint64_t compact_bytes = (uint64_t)CompactRows(height, devices) * row;
+    unsigned k = 0;
+    if (part == Partition::kBands) {
+        for (unsigned d = 1; d < devices; d++) {
+            const RowBand b = BandOf(height, devices, d);
+            if (b.y1 > b.y0) ops[k++] = GatherOp{GatherOp::kRecvBand, d, b.y0 * row, b.y0 * row, (b.y1 - b.y0) * row, 0, 0, 1};
+        }
+        return k;
+    }
+    for (unsigned d = 1; d < devices; d++)
+        ops[k++] = GatherOp{GatherOp::kRecvCompact, d, 0, d * compact_bytes, compact_bytes, 0, 0, 1};
+    for (unsigned d = 0; d < devices; d++) {
+        const unsigned owned = StripsOwned(height, devices, d);
+        if (!owned) continue;
+        const unsigned last = d + (owned - 1) * devices;             // local strip j of device d is global strip d + j * devices
+        const bool cut = StripRowsInFrame(height, last) < kStripRows;
+        const unsigned whole = cut ? owned - 1 : owned;
+        if (whole) ops[k++] = GatherOp{GatherOp::kCopyStrips, d, d * compact_bytes, d * strip_bytes, strip_bytes, strip_bytes, devices * strip_bytes, whole};
+        if (cut) ops[k++] = GatherOp{GatherOp::kCopyCut, d, d * compact_bytes + (uint64_t)(owned - 1) * strip_bytes, last * strip_bytes,
+                                     StripRowsInFrame(height, last) * row, 0, 0, 1};
+    }
+    return k;
+}

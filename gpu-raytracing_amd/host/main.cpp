@@ -5,14 +5,15 @@
 //
 //   rt_cli <file.obj> [--type sah|bottom-up|hybrid] [--pairs] [--splits] [--render depth|boxtests|tritests|material|lods|diffuse|texture|texturelit|shadows]
 //          [--width W] [--height H] [--spp N] [--yaw Y --pitch P --pos X Y Z] [--out frame.ppm] [--frames K]
-//          [--path "<ev>,<ev>,..."] [--rebuild] [--gpus N [--partition bands|strips|auto]]
+//          [--path "<ev>,<ev>,..."] [--rebuild] [--gpus N [--partition bands|strips|auto] [--inflight K]]
 //   rt_cli - --grid G [--camera a|b] ...      (argv[1] stays the scene slot, as in the reference) the bench's synthetic scene: grid_mesh(G, 1) of
 //                                             gpu-raytracing_amd/scenes.py (G = 708: 1,002,528 triangles) and its camera A
 //                                             ("top-down") or B ("oblique"), SURVEY 8(d) -- the C++ host at the headline size
 //
 // --gpus N: the frame is traced by N GPUs of this node from this ONE process (MultiGpu.h): replicated build per device,
 // one row band (or interleaved strips) per device, one grouped RCCL send/recv per frame into device 0, counters summed by
-// ncclReduce.  --gpus 1 takes the same code path with a one-device communicator.
+// ncclReduce.  --gpus 1 takes the same code path with a one-device communicator.  --inflight K (default 1 = the reference's
+// enqueue-wait-present loop): K frames in flight, frame f in slot f mod K (own streams, buffers and communicators per slot).
 //
 // --path: one comma-separated entry per frame (repeated cyclically when shorter than --frames); an entry is a
 // concatenation of events applied BEFORE that frame is traced, in the order the GLUT callbacks would have run:
@@ -99,12 +100,12 @@ static RenderType ParseRender(const std::string& s)
 
 // --gpus N: Display() with the frame partitioned across N devices (static camera; the scripted input path and --rebuild
 // belong to the single-device loop below)
-static int RunMultiGpu(int gpus, Partition partition, const Scene& scene, const Arguments& args, const Camera& camera, int width,
+static int RunMultiGpu(int gpus, int inflight, Partition partition, const Scene& scene, const Arguments& args, const Camera& camera, int width,
                        int height, int frames, unsigned spp, const std::string& out)
 {
     const unsigned n = (unsigned)scene.triangles.size();
     const bool hybrid = args.build_type == kHybrid, sah = args.build_type == kSAH;
-    MultiGpuTracer mg(gpus);
+    MultiGpuTracer mg(gpus, inflight);
     mg.UploadScene(scene);
     const float build_ms = mg.Build(args);
     printf("%s time elapsed: %fms (%d replica%s, slowest)\n", sah ? "RunSahBuild" : "RunBottomUpBuild", build_ms, gpus, gpus == 1 ? "" : "s");
@@ -130,27 +131,39 @@ static int RunMultiGpu(int gpus, Partition partition, const Scene& scene, const 
     const int bad = VerifyHierarchy(nodes.data(), root_index, root_count);
 
     mg.Resize(width, height);
+    // Display()'s frame loop with `inflight` frames in flight: frame f is enqueued into slot f mod inflight; the frame that
+    // slot held (f - inflight) is taken -- waited for, counters read, reported -- just before.  inflight = 1 is the
+    // reference's loop: enqueue, wait, present.
     uint64_t tests[4] = {0, 0, 0, 0};
-    double total_ms = 0;
-    for (int f = 0; f < frames; f++) {
-        const auto t0 = std::chrono::steady_clock::now();
-        mg.TraceFrame(camera, args.render_type, root_index, root_count, spp, partition);
-        (void)mg.Frame();                                                   // the gathered frame is on device 0
-        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        total_ms += ms;
-        mg.Counters(tests);
-        const std::vector<float>& dms = mg.DeviceMs();
+    const int K = mg.inflight();
+    std::vector<std::chrono::steady_clock::time_point> issued((size_t)frames);
+    const auto loop0 = std::chrono::steady_clock::now();
+    auto take = [&](int f) {
+        const int slot = f % K;
+        (void)mg.Frame(slot);                                               // the gathered frame is on device 0
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - issued[(size_t)f]).count();
+        mg.Counters(tests, slot);
+        const std::vector<float>& dms = mg.DeviceMs(slot);
         if (f == 0) {
             printf("TraceRays time elapsed: %fms (host clock, %d device%s, gather included)\n", ms, gpus, gpus == 1 ? "" : "s");
             printf("TraceRays number of tests %llu\n", (unsigned long long)tests[0]);   // main.cu:180-183
         }
-        printf("frame %d: %s  %.3f ms  box tests %llu  triangle tests %llu  %.1f Mrays/s  per-device trace ms:", f,
-               mg.LastPartition() == Partition::kStrips ? "strips" : "bands", ms, (unsigned long long)tests[0],
-               (unsigned long long)tests[1], (double)width * height * spp / ms / 1e3);
+        printf("frame %d: %s  %.3f ms%s  box tests %llu  triangle tests %llu  %.1f Mrays/s  per-device trace ms:", f,
+               mg.LastPartition(slot) == Partition::kStrips ? "strips" : "bands", ms, K > 1 ? " (enqueue to taken)" : "",
+               (unsigned long long)tests[0], (unsigned long long)tests[1], (double)width * height * spp / ms / 1e3);
         for (float v : dms) printf(" %.3f", v);
         printf("\n");
+    };
+    for (int f = 0; f < frames; f++) {
+        if (f >= K) take(f - K);
+        issued[(size_t)f] = std::chrono::steady_clock::now();
+        mg.TraceFrame(camera, args.render_type, root_index, root_count, spp, partition);
     }
-    if (frames > 1) printf("%d frames: mean %fms = %.1f fps\n", frames, total_ms / frames, 1e3 * frames / total_ms);
+    for (int f = frames > K ? frames - K : 0; f < frames; f++) take(f);
+    const double total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - loop0).count();
+    if (frames > 1)
+        printf("%d frames, %d in flight: mean %fms = %.1f fps = %.1f Mrays/s\n", frames, K, total_ms / frames, 1e3 * frames / total_ms,
+               (double)width * height * spp * frames / total_ms / 1e3);
     if (!out.empty()) {
         std::vector<uint8_t> frame;
         mg.FrameToHost(frame);
@@ -175,6 +188,7 @@ int main(int argc, char** argv)
     std::string out, path;
     bool rebuild = false;
     int gpus = 0;                                              // 0: the single-device path of the reference
+    int inflight = 1;                                          // --gpus N: frames in flight (MultiGpu.h)
     Partition partition = Partition::kAuto;
     uint32_t grid = 0;                                         // --grid G: synthetic scene instead of argv[1]
     char grid_camera = 0;
@@ -193,6 +207,7 @@ int main(int argc, char** argv)
         else if (a == "--path") { path = next(1); i++; }
         else if (a == "--rebuild") { rebuild = true; }
         else if (a == "--gpus") { gpus = atoi(next(1)); i++; }
+        else if (a == "--inflight") { inflight = atoi(next(1)); i++; }
         else if (a == "--grid") { grid = (uint32_t)atoi(next(1)); i++; }
         else if (a == "--camera") { grid_camera = next(1)[0]; i++; }
         else if (a == "--partition") {
@@ -226,7 +241,7 @@ int main(int argc, char** argv)
     UpdateCamera(camera[0]);
     camera.toDevice();
 
-    if (gpus > 0) return RunMultiGpu(gpus, partition, scene, args, camera[0], width, height, frames, spp, out);
+    if (gpus > 0) return RunMultiGpu(gpus, inflight, partition, scene, args, camera[0], width, height, frames, spp, out);
 
     // frame 0 of Display(): the four device buffers, upload, build, read back, count, verify (main.cu:226-259)
     BuildInput in{};

@@ -103,5 +103,18 @@ unsigned rth_strips_owned(unsigned height, unsigned devices, unsigned d) { retur
 unsigned rth_compact_rows(unsigned height, unsigned devices) { return CompactRows(height, devices); }
 unsigned rth_strip_rows_in_frame(unsigned height, unsigned s) { return StripRowsInFrame(height, s); }
 int rth_choose_partition(const double* costs, unsigned devices) { return (int)ChoosePartition(costs, devices); }
+// GatherPlan: out[k] = {kind, device, src_off, dst_off, bytes, src_pitch, dst_pitch, pieces} as uint64; returns the op count
+unsigned rth_gather_plan(unsigned width, unsigned height, unsigned devices, int strips, uint64_t* out)
+{
+    GatherOp ops[kMaxGatherOps];
+    if (devices == 0 || devices > 64) return 0;
+    const unsigned k = GatherPlan(width, height, devices, strips ? Partition::kStrips : Partition::kBands, ops);
+    for (unsigned i = 0; i < k; i++) {
+        const GatherOp& o = ops[i];
+        const uint64_t v[8] = {o.kind, o.device, o.src_off, o.dst_off, o.bytes, o.src_pitch, o.dst_pitch, o.pieces};
+        for (int j = 0; j < 8; j++) out[i * 8 + j] = v[j];
+    }
+    return k;
+}
 
 }  // extern "C"

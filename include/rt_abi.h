@@ -181,7 +181,8 @@ int rt_generate_morton_codes(uint32_t* codes, uint32_t* values, const rt_triangl
                              const int32_t* aabb_ordered, uint32_t n, void* stream);
 
 /* replaces RadixSort (RadixSort.cuh:6-7, RadixSort.cu:171-225): stable ascending sort of (key,value)
- * pairs, result in keys/values, tmp_* are n-entry temporaries.  sort_scratch: >= rt_radix_sort_scratch_bytes(n). */
+ * pairs, result in keys/values, tmp_* are n-entry temporaries.  sort_scratch: >= rt_radix_sort_scratch_bytes(n).
+ * count <= 0x3FFFFFFF (the kernels address the arrays with 32-bit byte offsets); larger -> RT_ERR_TOO_LARGE, nothing runs. */
 size_t rt_radix_sort_scratch_bytes(uint32_t count);
 int rt_radix_sort_u32_pairs(uint32_t* keys, uint32_t* values, uint32_t* tmp_keys, uint32_t* tmp_values,
                             uint32_t count, void* sort_scratch, void* stream);

@@ -197,3 +197,72 @@ def test_partition_arithmetic_matches_the_python_harness():
     for costs in ([1.0], [1.0, 1.0], [0.02, 0.02, 0.85, 0.31], [1.0, 1.1, 1.0, 1.05], [0.0, 0.0], [1.0, 1.16, 1.0, 0.84]):
         arr = (ctypes.c_double * len(costs))(*costs)
         assert ("bands", "strips")[L.rth_choose_partition(arr, len(costs))] == sh.choose_partition(costs)
+
+
+@pytest.mark.parametrize("strips", [False, True])
+def test_multi_gpu_gather_plan_writes_every_row_once(strips):
+    """host/MultiGpu.cpp::TraceFrame executes Partition.h::GatherPlan -- the receives into device 0 (band rows straight
+    into the frame; compact strip buffers into staging slots) and, for strips, one strided copy per source device plus a
+    plain copy for a strip the frame's edge cuts.  A multi-GPU node is not available to the tests, so the plan is replayed
+    here on numpy buffers for 1 - 8 devices, odd widths and ragged heights: each device 'renders' its rows as (row label,
+    device) and after the replay every row of device 0's frame must hold its own label from its owner, written exactly
+    once (a wrong offset, pitch, piece count or cut-strip copy shows up as a missing, doubled or misplaced row)."""
+    import ctypes
+    L = _hostlib()
+    L.rth_gather_plan.restype = ctypes.c_uint
+    L.rth_gather_plan.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
+    for fn in (L.rth_strips_owned, L.rth_compact_rows, L.rth_strip_rows_in_frame):
+        fn.restype = ctypes.c_uint
+    buf = (ctypes.c_uint64 * (8 * 3 * 64))()
+    out2 = (ctypes.c_uint * 2)()
+    for W in (1, 5, 322):
+        row = W * 4
+        for H in (1, 7, 8, 9, 53, 203, 1080, 1081):
+            for P in range(1, 9):
+                nops = L.rth_gather_plan(W, H, P, int(strips), buf)
+                ops = np.frombuffer(buf, np.uint64, nops * 8).reshape(nops, 8).astype(np.int64)
+                crow = L.rth_compact_rows(H, P)
+                # what each device rendered: label = 1 + global row (0 = never written), second byte = device
+                frames = [np.zeros((H, row), np.uint16) for _ in range(P)]        # bands: in place in the device's own frame
+                compact = [np.zeros((crow, row), np.uint16) for _ in range(P)]   # strips: compact buffers
+                owner = np.full(H, -1)
+                for d in range(P):
+                    if strips:
+                        for j in range(L.rth_strips_owned(H, P, d)):
+                            s = d + j * P
+                            for r in range(L.rth_strip_rows_in_frame(H, s)):
+                                compact[d][j * 8 + r] = (s * 8 + r + 1) | (d << 12)
+                                owner[s * 8 + r] = d
+                    else:
+                        L.rth_band_of(H, P, d, out2)
+                        for y in range(out2[0], out2[1]):
+                            frames[d][y] = (y + 1) | (d << 12)
+                            owner[y] = d
+                assert (owner >= 0).all()
+                dst = frames[0].view(np.uint8).reshape(-1).copy() if not strips else np.zeros(H * row * 2, np.uint8)
+                writes = np.zeros(H * row * 2, np.int32)
+                if not strips:
+                    L.rth_band_of(H, P, 0, out2)
+                    writes[out2[0] * row * 2: out2[1] * row * 2] += 1              # device 0's band is in place
+                staging = np.zeros(P * crow * row * 2, np.uint8)
+                staging[: crow * row * 2] = compact[0].view(np.uint8).reshape(-1)  # device 0 renders into staging slot 0
+                for kind, dev, src_off, dst_off, nbytes, sp, dp, pieces in ops:
+                    # (offsets are in bytes of RGBA8 rows; the replay's rows are uint16 per byte -> scale by 2)
+                    so, do, nb, sp, dp = src_off * 2, dst_off * 2, nbytes * 2, sp * 2, dp * 2
+                    if kind == 0:      # kRecvBand: sender's frame -> device 0's frame
+                        dst[do:do + nb] = frames[dev].view(np.uint8).reshape(-1)[so:so + nb]
+                        writes[do:do + nb] += 1
+                    elif kind == 1:    # kRecvCompact: sender's compact buffer -> staging
+                        assert dev >= 1 and nb == crow * row * 2
+                        staging[do:do + nb] = compact[dev].view(np.uint8).reshape(-1)[so:so + nb]
+                    elif kind == 2:    # kCopyStrips: `pieces` pieces of nbytes, strided
+                        for q in range(pieces):
+                            dst[do + q * dp: do + q * dp + nb] = staging[so + q * sp: so + q * sp + nb]
+                            writes[do + q * dp: do + q * dp + nb] += 1
+                    else:              # kCopyCut
+                        dst[do:do + nb] = staging[so:so + nb]
+                        writes[do:do + nb] += 1
+                assert (writes == 1).all(), (W, H, P, strips, "a byte of the frame written %d..%d times" % (writes.min(), writes.max()))
+                got = dst.view(np.uint16).reshape(H, row)
+                exp = ((np.arange(H) + 1) | (owner << 12)).astype(np.uint16)
+                assert (got == exp[:, None]).all(), (W, H, P, strips)
