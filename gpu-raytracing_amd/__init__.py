@@ -244,7 +244,8 @@ def SahMemoryRequirements(num_triangles: int) -> int:
 
 
 def RunSahBuild(inp: BuildInput, args: Optional[Arguments] = None, stream=None) -> None:
-    """BuildWrapper.cu:140-251.  Trace root = (0, 1).  Synchronises `stream` (data-dependent number of levels)."""
+    """BuildWrapper.cu:140-251.  Trace root = (0, 1).  Asynchronous on `stream` (no copy, no synchronisation: graph-capturable);
+    error flags in the scratch status word (sah_scratch_layout(n).status)."""
     args = args or Arguments(build_type=kSAH)
     ci = _BuildInput(_ptr(inp.triangles_in), _ptr(inp.triangles_out), inp.num_triangles, _ptr(inp.nodes_out),
                      _ptr(inp.scratch))

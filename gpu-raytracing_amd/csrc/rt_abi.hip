@@ -1,8 +1,8 @@
 // rt_abi.hip -- the extern "C" entry points declared in include/rt_abi.h.
 // Host orchestration only: scratch carving and kernel order (the role of BuildWrapper.cu:68-136,
 // 253-362 and main.cu:125-192 in the reference).  No allocation, no host<->device copies of data: every call is a
-// sequence of asynchronous launches on the caller's stream (rt_run_sah_build alone synchronises: its number of
-// levels is data dependent).
+// sequence of asynchronous launches on the caller's stream (rt_run_sah_build too: its number of launches is fixed by
+// n, the data-dependent tail is a device-side loop, sah_build.hip).
 #include "rt_device.hpp"
 #include "rt_launch.hpp"
 
@@ -214,11 +214,9 @@ int rt_run_sah_build(const rt_build_input* input, const rt_arguments* args, void
     if ((reinterpret_cast<uintptr_t>(input->scratch) & 255u) || (reinterpret_cast<uintptr_t>(input->triangles_in) & 15u) ||
         (reinterpret_cast<uintptr_t>(input->triangles_out) & 63u) || (reinterpret_cast<uintptr_t>(input->nodes_out) & 63u))
         return RT_ERR_INVALID_ARGUMENT;
-    uint32_t status0 = 0;
-    const hipError_t e = launch_sah_build(input->triangles_in, n, args && args->enable_pairs, splits, input->triangles_out,
-                                          input->nodes_out, input->scratch, static_cast<hipStream_t>(stream), nullptr, &status0);
-    if (e != hipSuccess) return hip_rc(e);
-    return status0 ? RT_ERR_BUILD_INCOMPLETE : RT_OK;
+    // asynchronous, like the bottom-up build: the error flags stay in the scratch status word (rt_sah_scratch_layout.status)
+    return hip_rc(launch_sah_build(input->triangles_in, n, args && args->enable_pairs, splits, input->triangles_out,
+                                   input->nodes_out, input->scratch, static_cast<hipStream_t>(stream), nullptr, nullptr));
 }
 
 static int trace_common(const rt_accel* as, const rt_scene* scene, uint64_t* counters, int render_type, uint8_t* rgba8,

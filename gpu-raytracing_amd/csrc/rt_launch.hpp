@@ -155,8 +155,8 @@ hipError_t launch_radix_pass(const uint32_t* keys_in, const uint32_t* vals_in, u
 // --pairs leaf slots: merge flag per candidate (2k, 2k+1), per-workgroup slot offsets, *num_leaves = L
 hipError_t launch_pair_slots(const rt_triangle* tris, uint32_t n, uint8_t* flags, uint32_t* block_sums,
                              uint32_t* num_leaves, hipStream_t st);
-// RunSahBuild.  Synchronises the stream (data-dependent number of levels).  *status0 (may be null) = the build's error
-// flags as read back with the live-task counter: non-zero means the tree is incomplete.
+// RunSahBuild.  Asynchronous (a fixed number of launches; nothing is read back).  *levels_run (may be null) = level launches
+// enqueued; *status0 (may be null) is set to 0 -- the error flags live in the scratch status word.
 hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, bool splits, rt_triangle_pair* leaves,
                             rt_node* nodes, void* scratch, hipStream_t st, uint32_t* levels_run, uint32_t* status0 = nullptr);
 // in-place exclusive scan of per-workgroup sums (one workgroup); *total = their sum

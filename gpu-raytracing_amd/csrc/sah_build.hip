@@ -22,8 +22,12 @@
 //     kernel needs to agree on an order and the top tree is built in the same launches as the cell trees;
 //   * leaf slots = input order (pairs: prefix sums), cell members by one stable 8-bit radix pass (radix_sort.hip).
 //
-// The level loop's length is data dependent; like the reference (which reads num_leaves back, BuildWrapper.cu:229)
-// the host synchronises: after the first batch of levels it reads the number of live tasks, then once per batch.
+// The depth of the trees is data dependent; the reference reads num_leaves back and loops on the host
+// (BuildWrapper.cu:229).  Here the number of LAUNCHES is fixed by n: the level loop runs log2(items per cell / 64) + 3
+// levels (kernels of a level nobody reaches return at once), then sah_finish_kernel finishes whatever is still larger
+// than 64 items, one workgroup per task, then sah_small_kernel.  No copy, no synchronisation: rt_run_sah_build is a
+// sequence of asynchronous launches (hipGraph-capturable, tests/test_gpu_graph.py); its error flags stay in the scratch
+// status word like the bottom-up build's.
 #include "rt_device.hpp"
 #include "rt_launch.hpp"
 #include "rt_pairing.hpp"
@@ -789,6 +793,54 @@ __device__ __forceinline__ void ibox_to_float(const int* b, float* f)
     for (int k = 0; k < 6; k++) f[k] = ordered_int_to_float(b[k]);
 }
 
+// SelectPlane (SharedTaskBuilder.cu:297-350) on the 8 bins of one task (g: [8][kBinWords] ordered ints, max words NOT
+// complemented): the binned split with the lowest SAH score (sweep right -> left, strict <, both sides non-empty: the
+// highest plane wins ties) -> kind 1, plane, mid and the children's boxes cb[side][p box 6, c box 6]; no such plane:
+// kind, plane, mid and cb stay as they were (the caller's object-median split).  One thread; shared by the level loop
+// (sah_split_kernel) and the straggler kernel (sah_finish_kernel) so that both pick bit-identical planes.
+__device__ __forceinline__ void sah_select_plane(const int* g, uint32_t start, uint32_t& kind, uint32_t& plane, uint32_t& mid, int (*cb)[12])
+{
+    // prefix left -> right: surface area and count of bins [0, i]
+    float sa_l[7];
+    uint32_t ln[7];
+    {
+        int run[6] = {kEmptyLo, kEmptyLo, kEmptyLo, kEmptyHi, kEmptyHi, kEmptyHi};
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            ibox_merge(run, g + i * kBinWords);
+            c += (uint32_t)g[i * kBinWords + 12];
+            float f[6];
+            ibox_to_float(run, f);
+            sa_l[i] = sah_sa(f);
+            ln[i] = c;
+        }
+    }
+    int run[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) run[k] = g[7 * kBinWords + k];
+    uint32_t rn = (uint32_t)g[7 * kBinWords + 12];
+    float best = 3.402823466e+38f;
+    int pl = -1;
+#pragma unroll
+    for (int i = 6; i >= 0; i--) {
+        float f[6];
+        ibox_to_float(run, f);
+        const float score = sa_l[i] * (float)ln[i] + sah_sa(f) * (float)rn;
+        if (score < best && ln[i] && rn) { best = score; pl = i; }
+        ibox_merge(run, g + i * kBinWords);
+        rn += (uint32_t)g[i * kBinWords + 12];
+    }
+    if (pl >= 0) {
+        kind = 1; plane = (uint32_t)pl; mid = start + ln[pl];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (i <= pl) { ibox_merge(&cb[0][0], g + i * kBinWords); ibox_merge(&cb[0][6], g + i * kBinWords + 6); }
+            else { ibox_merge(&cb[1][0], g + i * kBinWords); ibox_merge(&cb[1][6], g + i * kBinWords + 6); }
+        }
+    }
+}
+
 // wave-aggregated counter bump: lanes with `want` get consecutive values, one atomic per wave
 __device__ __forceinline__ uint32_t wave_alloc(uint32_t* counter, bool want, uint32_t lane)
 {
@@ -850,49 +902,7 @@ __global__ __launch_bounds__(kSplitWaves * 64) void sah_split_kernel(SahArgs a, 
 #pragma unroll
         for (int k = 0; k < 12; k++) cb[s][k] = (k % 6) < 3 ? kEmptyLo : kEmptyHi;
     uint32_t mid = 0, kind = 2, plane = 0;
-    if (valid && !(sah_sa(T.c) <= 0.0f)) {
-        const int* g = &sbins[lane * kRow];
-        // prefix left -> right: surface area and count of bins [0, i]
-        float sa_l[7];
-        uint32_t ln[7];
-        {
-            int run[6] = {kEmptyLo, kEmptyLo, kEmptyLo, kEmptyHi, kEmptyHi, kEmptyHi};
-            uint32_t c = 0;
-#pragma unroll
-            for (int i = 0; i < 7; i++) {
-                ibox_merge(run, g + i * kBinWords);
-                c += (uint32_t)g[i * kBinWords + 12];
-                float f[6];
-                ibox_to_float(run, f);
-                sa_l[i] = sah_sa(f);
-                ln[i] = c;
-            }
-        }
-        // sweep right -> left, strict <, both sides non-empty: the highest plane wins ties
-        int run[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) run[k] = g[7 * kBinWords + k];
-        uint32_t rn = (uint32_t)g[7 * kBinWords + 12];
-        float best = 3.402823466e+38f;
-        int pl = -1;
-#pragma unroll
-        for (int i = 6; i >= 0; i--) {
-            float f[6];
-            ibox_to_float(run, f);
-            const float score = sa_l[i] * (float)ln[i] + sah_sa(f) * (float)rn;
-            if (score < best && ln[i] && rn) { best = score; pl = i; }
-            ibox_merge(run, g + i * kBinWords);
-            rn += (uint32_t)g[i * kBinWords + 12];
-        }
-        if (pl >= 0) {
-            kind = 1; plane = (uint32_t)pl; mid = T.start + ln[pl];
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                if (i <= pl) { ibox_merge(&cb[0][0], g + i * kBinWords); ibox_merge(&cb[0][6], g + i * kBinWords + 6); }
-                else { ibox_merge(&cb[1][0], g + i * kBinWords); ibox_merge(&cb[1][6], g + i * kBinWords + 6); }
-            }
-        }
-    }
+    if (valid && !(sah_sa(T.c) <= 0.0f)) sah_select_plane(&sbins[lane * kRow], T.start, kind, plane, mid, cb);
     if (valid && kind == 2) mid = T.start + (count >> 1);
     // object split at the midpoint: child boxes by a wave reduction over the items, one task at a time
     for (uint64_t todo = __builtin_amdgcn_ballot_w64(valid && kind == 2); todo; todo &= todo - 1) {
@@ -1307,9 +1317,154 @@ __device__ __forceinline__ void sah_small_task(const SahArgs& a, SmallSmem& S, u
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Stragglers.  The level loop is a FIXED number of launches (the host never reads the number of live tasks back, so the
+// build is a plain sequence of asynchronous launches like the LBVH and can be captured in a hipGraph); tasks that still
+// hold more than kSahSmall items after it -- unbalanced splits: a few tasks on ordinary scenes, deep chains on scenes
+// that span many octaves -- are finished here, ONE WORKGROUP PER TASK, the way the reference builds a whole grid cell
+// with one block looping over a task queue (SharedTaskBuild's main loop, SharedTaskBuilder.cu:909-967): pop a task, bin
+// its items into LDS, select the plane (the same function as the level loop: bit-identical planes), write the parent
+// descriptor, partition stably into the other id buffer, push the children that are still large (the smaller one on top:
+// the stack stays below log2 of the task size) and queue the small ones for sah_small_kernel, which runs after this
+// kernel.  Node slots are a function of the split position, so the order tasks are processed in does not matter.
+constexpr uint32_t kFinThreads = 256, kFinStack = 64, kFinGrid = 1024;
+
+__global__ __launch_bounds__(kFinThreads) void sah_finish_kernel(SahArgs a, uint32_t lvl)
+{
+    const uint32_t ntask = a.H->level_count[lvl];
+    if (blockIdx.x >= ntask) return;
+    __shared__ SahTask stack[kFinStack];     // flags: bit 0 top tree, bit 1 the id buffer the task's items are in
+    __shared__ uint32_t sp, s_kind, s_plane, s_mid;
+    __shared__ int sb[8 * kBinWords];        // the task's bins: the global form (max words complemented) while they fill
+    __shared__ int scb[2][12];               // the children's boxes [side][p box 6, c box 6], ordered ints
+    __shared__ uint32_t ws[8];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t task = blockIdx.x; task < ntask; task += gridDim.x) {
+        if (tid == 0) {
+            SahTask T = a.tasks[lvl & 1u][task];
+            T.flags = (T.flags & 1u) | ((lvl & 1u) << 1);
+            stack[0] = T;
+            sp = 1;
+        }
+        __syncthreads();
+        while (true) {
+            const uint32_t depth = sp;       // (uniform: written before the last barrier)
+            if (depth == 0) break;
+            const SahTask T = stack[depth - 1];
+            const uint32_t cur = (T.flags >> 1) & 1u, nxt = cur ^ 1u;
+            const uint32_t count = T.end - T.start;
+            for (uint32_t j = tid; j < 8 * kBinWords; j += kFinThreads) sb[j] = (j % kBinWords) == 12 ? 0 : kEmptyLo;
+            if (tid < 24) scb[tid / 12][tid % 12] = (tid % 6) < 3 ? kEmptyLo : kEmptyHi;
+            __syncthreads();                 // everybody holds T; the tables are clear
+            if (tid == 0) { sp = depth - 1; s_kind = 2; s_plane = 0; s_mid = T.start + (count >> 1); }
+            // ---- BinCentroids (SharedTaskBuilder.cu:206-264), as sah_bin_kernel
+            if (!(sah_sa(T.c) <= 0.0f)) {
+                const int axis = sah_axis(T.c);
+                const float epsilon = 1.1920929e-7f;
+                const float cmin = axis == 0 ? T.c[0] : (axis == 1 ? T.c[1] : T.c[2]);
+                const float cmax = axis == 0 ? T.c[3] : (axis == 1 ? T.c[4] : T.c[5]);
+                const float k1 = 8 * (1 - epsilon) / (cmax - cmin);
+                for (uint32_t i = T.start + tid; i < T.end; i += kFinThreads) {
+                    float b[6], ctr[3];
+                    load_box(a.aabbs, a.ids[cur][i], b);
+#pragma unroll
+                    for (int k = 0; k < 3; k++) ctr[k] = (b[k] + b[3 + k]) * 0.5f;
+                    const float ca = axis == 0 ? ctr[0] : (axis == 1 ? ctr[1] : ctr[2]);
+                    const int bin = min(7, max(0, cvt_rzi(k1 * (ca - cmin))));
+                    a.binof[i] = (uint8_t)bin;
+                    int* lb = &sb[bin * kBinWords];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        atomicMin(&lb[k], float_to_ordered_int(b[k]));
+                        atomicMin(&lb[3 + k], ~float_to_ordered_int(b[3 + k]));
+                        atomicMin(&lb[6 + k], float_to_ordered_int(ctr[k]));
+                        atomicMin(&lb[9 + k], ~float_to_ordered_int(ctr[k]));
+                    }
+                    atomicAdd(&lb[12], 1);
+                }
+                __syncthreads();
+                if (tid < 8 * kBinWords) {   // the form SelectPlane reads: max words as they are
+                    const uint32_t wd = tid % kBinWords;
+                    if (wd < 12 && (wd % 6) >= 3) sb[tid] = ~sb[tid];
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    uint32_t kind = 2, plane = 0, mid = T.start + (count >> 1);
+                    sah_select_plane(sb, T.start, kind, plane, mid, scb);
+                    s_kind = kind; s_plane = plane; s_mid = mid;
+                }
+            }
+            __syncthreads();
+            const uint32_t kind = s_kind, plane = s_plane, mid = s_mid;
+            // ---- the children's boxes of an object-median split (SharedTaskBuilder.cu:465-510) and the stable partition
+            // (PartitionIds, :352-380) into the other id buffer
+            if (kind == 2) {
+                for (uint32_t i = T.start + tid; i < T.end; i += kFinThreads) {
+                    const uint32_t id = a.ids[cur][i];
+                    float b[6];
+                    load_box(a.aabbs, id, b);
+                    int* v = &scb[i >= mid ? 1 : 0][0];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        const int ctr = float_to_ordered_int((b[3 + k] + b[k]) * 0.5f);
+                        atomicMin(&v[k], float_to_ordered_int(b[k]));
+                        atomicMax(&v[3 + k], float_to_ordered_int(b[3 + k]));
+                        atomicMin(&v[6 + k], ctr);
+                        atomicMax(&v[9 + k], ctr);
+                    }
+                    a.ids[nxt][i] = id;
+                }
+            } else {
+                uint32_t running = 0;        // items that went left so far
+                for (uint32_t base = T.start; base < T.end; base += kFinThreads) {
+                    const uint32_t i = base + tid;
+                    const bool in = i < T.end;
+                    const bool left = in && a.binof[i] <= plane;   // (written by this very thread above)
+                    uint32_t total;
+                    const uint32_t ex = block_excl_scan_u32<kFinThreads>(left ? 1u : 0u, ws, &total);
+                    if (in) {
+                        const uint32_t lr = running + ex;
+                        a.ids[nxt][left ? T.start + lr : mid + ((i - T.start) - lr)] = a.ids[cur][i];
+                    }
+                    running += total;
+                }
+            }
+            // the ids written above are read by OTHER threads of this workgroup when a child is popped: complete and
+            // visible before the barrier
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+            __syncthreads();
+            if (tid == 0) {
+                const int bias = (T.flags & 1u) ? -2 * (int)a.B : (int)(2 * kSahCells);
+                const uint32_t child_index = (uint32_t)(bias + 2 * (int)mid);
+                sah_put_node(a.nodes + T.parent_idx, T.p, child_index, 2u, RT_CHILD_BOX);
+                // larger child first, so that the smaller one is popped next
+                const int order0 = (mid - T.start) >= (T.end - mid) ? 0 : 1;
+                uint32_t top = depth - 1;
+                for (int q = 0; q < 2; q++) {
+                    const int sd = q == 0 ? order0 : 1 - order0;
+                    const uint32_t cs = sd ? mid : T.start, ce = sd ? T.end : mid;
+                    if (ce - cs > kSahSmall) {
+                        if (top >= kFinStack) { atomicOr(&a.H->status[0], kSahErrLevels); continue; }   // cannot happen: < 2 * log2(items) entries
+                        SahTask C;
+#pragma unroll
+                        for (int k = 0; k < 6; k++) { C.p[k] = ordered_int_to_float(scb[sd][k]); C.c[k] = ordered_int_to_float(scb[sd][6 + k]); }
+                        C.start = cs; C.end = ce; C.parent_idx = child_index + (uint32_t)sd; C.flags = (T.flags & 1u) | (nxt << 1);
+                        stack[top++] = C;
+                    } else {
+                        const uint32_t q2 = atomicAdd(&a.H->small_count, 1u);
+                        a.small[q2] = SahSmall{cs, ce, child_index + (uint32_t)sd, (T.flags & 1u) | (nxt << 1)};
+                    }
+                }
+                sp = top;
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+    }
+}
+
 // The small tasks [first, H->small_count): a fixed grid, every wave takes tasks with a grid stride.  The count is read
-// on the device, so the launch needs no host round trip after the level loop (68 us between the last level and this
-// kernel in round 1's timeline); `first` > 0 only when a later batch of levels appended more tasks.
+// on the device: no host round trip.
 __global__ __launch_bounds__(kSmallWaves * 64) void sah_small_kernel(SahArgs a, uint32_t first)
 {
     __shared__ SmallSmem SS[kSmallWaves];
@@ -1458,50 +1613,23 @@ hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, boo
     const uint32_t split_blocks = (TA + 63) / 64 > 2048 / 8 ? (TA + 63) / 64 : (TA < 2048 ? (TA + 7) / 8 : 2048 / 8);
     uint32_t lvl = 0;
     // levels until every task has <= kSahSmall items: about log2(items per cell / kSahSmall) when the splits are
-    // balanced; the first batch adds a margin, later batches are short
+    // balanced, plus a margin.  The number of launches is FIXED by n: kernels of a level nobody reaches return at once
+    // (level_count[lvl] == 0), and whatever is still alive after the last level is finished by sah_finish_kernel, one
+    // workgroup per task.  Nothing is read back: the build is a sequence of asynchronous launches.
     uint32_t batch = 3;
     for (uint32_t per_cell = a.B / kSahCells; per_cell > kSahSmall; per_cell >>= 1) batch++;
-    // After each batch of levels the small-task kernel and the top-tree patch are launched at once (their counts live on the
-    // device); only then does the host read the number of live tasks.  In the common case (the first batch finished every
-    // task) that read is the build's final synchronisation and nothing waits for it.
     constexpr uint32_t kSmallGrid = 32768 / kSmallWaves;
-    uint32_t small_done = 0;
-    while (true) {
-        for (uint32_t i = 0; i < batch && lvl + 1 < kSahMaxLevels; i++, lvl++) {
-            sah_bin_kernel<<<chunks, 256, 0, st>>>(a, lvl);
-            sah_split_kernel<<<split_blocks, kSplitWaves * 64, 0, st>>>(a, lvl);
-            sah_partition_kernel<<<chunks, 256, 0, st>>>(a, lvl);
-        }
-        sah_small_kernel<<<kSmallGrid, kSmallWaves * 64, 0, st>>>(a, small_done);
-        // The patch copies every cell's sub-root descriptor (w12 / w28 of the cell tree's root slot) into its top-tree leaf,
-        // guarded by "not patched yet" (count bits == 0), so the copy made after the FIRST batch is final.  Invariant: a
-        // cell's root is a level-0 task (or a small task queued by sah_roots_kernel), and the first batch runs at least
-        // three levels plus the small-task kernel, so every cell root has written its descriptor before this launch; later
-        // batches only finish tasks deeper in the trees and find nothing left to patch.
-        sah_patch_top_kernel<<<1, 128, 0, st>>>(a, splits ? 1 : 0, lvl);
-        // status[0..7], small_count and live_report are adjacent in SahHeader: ONE device-to-host copy (two copies into
-        // pageable host memory cost a host round trip each: 19 us between them in round 3's timeline)
-        uint32_t hdr[10] = {0};
-        static_assert(offsetof(SahHeader, small_count) == offsetof(SahHeader, status) + 32 &&
-                      offsetof(SahHeader, live_report) == offsetof(SahHeader, status) + 36, "one copy reads all three");
-        e = hipMemcpyAsync(hdr, &a.H->status[0], sizeof hdr, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) return e;
-        const uint32_t live = hdr[9];
-        small_done = hdr[8];
-        if (status0) *status0 = hdr[0];
-        if (levels_run) *levels_run = lvl;           // (also on the error returns below)
-        if (hdr[0] != 0) return hipSuccess;          // a kernel flagged an incomplete build (kSahErrLocals): stop here
-        if (live == 0) break;
-        if (lvl + 1 >= kSahMaxLevels) {
-            const uint32_t flag = hdr[0] | kSahErrLevels;
-            if (status0) *status0 = flag;
-            (void)hipMemcpyAsync(&a.H->status[0], &flag, 4, hipMemcpyHostToDevice, st);
-            (void)hipStreamSynchronize(st);
-            return hipSuccess;
-        }
-        batch = 4;
+    for (uint32_t i = 0; i < batch && lvl + 1 < kSahMaxLevels; i++, lvl++) {
+        sah_bin_kernel<<<chunks, 256, 0, st>>>(a, lvl);
+        sah_split_kernel<<<split_blocks, kSplitWaves * 64, 0, st>>>(a, lvl);
+        sah_partition_kernel<<<chunks, 256, 0, st>>>(a, lvl);
     }
+    sah_finish_kernel<<<kFinGrid, kFinThreads, 0, st>>>(a, lvl);
+    sah_small_kernel<<<kSmallGrid, kSmallWaves * 64, 0, st>>>(a, 0u);
+    // The patch copies every cell's sub-root descriptor (w12 / w28 of the cell tree's root slot) into its top-tree leaf.
+    // Invariant: a cell's root is a level-0 task, a straggler's ancestor or a small task queued by sah_roots_kernel -- all
+    // of them have written their descriptor when the three kernels above are done.
+    sah_patch_top_kernel<<<1, 128, 0, st>>>(a, splits ? 1 : 0, lvl);
     if (levels_run) *levels_run = lvl;
     return hipGetLastError();
 }

@@ -20,5 +20,6 @@ size_t BuMemoryRequirements(uint32_t num_triangles);                       // Bu
 void RunBottomUpBuild(BuildInput input, Arguments args, bool hybrid, void* stream = nullptr);  // BuildWrapper.cu:253-362
 size_t SahMemoryRequirements(uint32_t num_triangles);                      // BuildWrapper.cu:126-130
 // SAH build (args.enable_pairs, args.enable_splits as in the reference).  Trace root = (0, 1) (main.cu:222-223).
-// Synchronises `stream`: the number of build levels is data dependent (the reference syncs too, BuildWrapper.cu:229).
+// Asynchronous on `stream` like RunBottomUpBuild (the reference reads num_leaves back and loops on the host,
+// BuildWrapper.cu:229; here the data-dependent tail is a device-side loop).  Error flags: the scratch status word.
 void RunSahBuild(BuildInput input, Arguments args, void* stream = nullptr);  // BuildWrapper.cu:140-251

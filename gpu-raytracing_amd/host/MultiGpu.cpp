@@ -5,7 +5,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <thread>
 
 #include "MemoryBuffer.h"
 
@@ -133,9 +132,8 @@ float MultiGpuTracer::Build(const Arguments& args)
 {
     sah_ = args.build_type == kSAH;
     const bool hybrid = args.build_type == kHybrid;
-    // The bottom-up build is a sequence of asynchronous launches: one host thread issues it on every device and the devices
-    // build concurrently.  RunSahBuild reads a few words back per batch of levels (a data-dependent level count, as in the
-    // reference: BuildWrapper.cu:229) and so blocks its caller: each device's SAH build is issued by a thread of its own.
+    // Both builds are sequences of asynchronous launches (RunSahBuild since round 4: its data-dependent tail is a device-side
+    // loop): one host thread issues them on every device and the devices build concurrently.
     auto build_one = [&](size_t d) {
         Replica& r = dev_[d];
         DevSlot& x = slot_[0].dev[d];
@@ -144,13 +142,7 @@ float MultiGpuTracer::Build(const Arguments& args)
         if (sah_) RunSahBuild(r.in, args, x.stream); else RunBottomUpBuild(r.in, args, hybrid, x.stream);
         check(hipEventRecord(x.e1, x.stream));
     };
-    if (sah_ && dev_.size() > 1) {
-        std::vector<std::thread> th;
-        for (size_t d = 0; d < dev_.size(); d++) th.emplace_back(build_one, d);
-        for (std::thread& t : th) t.join();
-    } else {
-        for (size_t d = 0; d < dev_.size(); d++) build_one(d);
-    }
+    for (size_t d = 0; d < dev_.size(); d++) build_one(d);
     float worst = 0;
     for (size_t d = 0; d < dev_.size(); d++) {
         SetDevice(dev_[d]);

@@ -43,8 +43,8 @@ public:
     int inflight() const { return (int)slot_.size(); }
     // replicate triangles, attributes, materials and textures on every device (Scene::CopyToDevice, main.cu:421-456)
     void UploadScene(const Scene& scene);
-    // the same build on every device, concurrently (the SAH build synchronises its stream, so each device's build is issued
-    // by a host thread of its own); returns the slowest device's build time (ms).  Synchronises.
+    // the same build on every device, concurrently (both builders are asynchronous launch sequences); returns the slowest
+    // device's build time (ms).  Synchronises.
     float Build(const Arguments& args);
     // frame buffers for a width x height frame (per slot and device: full frame + compact strip buffer; staging on device 0)
     void Resize(int width, int height);

@@ -112,7 +112,7 @@ enum {
     RT_ERR_INVALID_ARGUMENT = -1,
     RT_ERR_UNSUPPORTED = -2,       /* (no option of the built paths returns it any more; kept for ABI stability) */
     RT_ERR_TOO_LARGE = -3,         /* n exceeds the 29-bit child index of Node (Common.cuh:152-159) */
-    RT_ERR_BUILD_INCOMPLETE = -4,  /* rt_run_sah_build: a kernel flagged the tree incomplete (status word, see rt_sah_scratch_layout) */
+    RT_ERR_BUILD_INCOMPLETE = -4,  /* (kept for ABI stability: rt_run_sah_build is asynchronous since round 4 and reports through the status word) */
     RT_ERR_HIP_BASE = -1000        /* -(hipError_t) + RT_ERR_HIP_BASE */
 };
 
@@ -145,8 +145,11 @@ size_t rt_sah_memory_requirements(uint32_t num_triangles);
  * while the running total of extra references -- taken in input order; an atomic counter in the reference -- stays
  * below n/5 (so L < n + n/5; n <= 2^25 with splits).
  * Same tree as the reference up to numbering, which is deterministic here: leaf slots in input order, node slots
- * = f(split position) (see gpu-raytracing_amd/csrc/sah_build.hip).  The number of build levels is data dependent:
- * like the reference (cudaMemcpy of num_leaves, BuildWrapper.cu:229) this call synchronises `stream`. */
+ * = f(split position) (see gpu-raytracing_amd/csrc/sah_build.hip).  The depth of the trees is data dependent and the
+ * reference loops on the host (cudaMemcpy of num_leaves, BuildWrapper.cu:229); here the number of launches is fixed by n
+ * and the data-dependent tail runs as a device-side loop: the call neither copies nor synchronises (hipGraph-capturable,
+ * like rt_run_bottom_up_build).  Error flags: the status word of the scratch (rt_sah_scratch_layout.status), 0 = complete
+ * tree, to be read by the caller after the stream has run. */
 int rt_run_sah_build(const rt_build_input* input, const rt_arguments* args, void* stream);
 
 typedef struct rt_sah_scratch_layout {
