@@ -154,7 +154,10 @@ def main():
     use_dist = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1"   # FORCE: 1-rank RCCL init + collectives (API check)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        if "MASTER_PORT" not in os.environ:          # (single-rank RCCL check: any free port)
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
@@ -281,6 +284,9 @@ def main():
     frame = frames[0]
     pending = [None] * S        # the collective that last used buffer k (or True when only the de-interleave is owed)
     counters = torch.zeros(4, dtype=torch.int64, device="cuda")
+    # the reference's Trace() resets and passes its num_tests buffer every frame (main.cu:153-157, Tracer.cu:503), and so
+    # does rt_cli: every timed frame does the same (one buffer per frame in flight, cleared on the frame's stream)
+    frame_counters = [torch.zeros(4, dtype=torch.int64, device="cuda") for _ in range(S)]
     step_no = [0]
 
     def finish(k):
@@ -300,10 +306,13 @@ def main():
             finish(k)
             if events is not None:
                 events[0].record()
+            ctr = counters if with_counters else frame_counters[k]
+            if not with_counters:
+                ctr.zero_()
             if strips:
-                trace_strips(compact[k], cam_key, args.render_type, counters if with_counters else None)
+                trace_strips(compact[k], cam_key, args.render_type, ctr)
             else:
-                trace_band(frames[k], cam_key, args.render_type, counters if with_counters else None)
+                trace_band(frames[k], cam_key, args.render_type, ctr)
             if events is not None:
                 events[1].record()
             if use_dist:
@@ -381,11 +390,12 @@ def main():
     iso = []
     for _ in range(24):
         e0, e1 = ev(), ev()
+        counters.zero_()
         e0.record()
         if strips:
-            trace_strips(compact[0], cam, iso_rt)
+            trace_strips(compact[0], cam, iso_rt, counters)
         else:
-            trace_band(scratch_frame, cam, iso_rt)
+            trace_band(scratch_frame, cam, iso_rt, counters)
         e1.record()
         e1.synchronize()
         iso.append(e0.elapsed_time(e1))
@@ -506,7 +516,7 @@ def main():
     rc = 0
     if rank == 0:
         # HBM bytes per launch from the PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md "HBM"): a counter
-        # pass cannot run inside this process, so the figure is the committed result of `tools/pmc_trace.sh` on this same
+        # pass cannot run inside this process, so the figure is the committed result of `tools/collect.sh run <round> pmc` on this same
         # command; it is attached only to the exact workload it was collected on and labelled with its source.
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "trace_traffic.json" if G == 708 else "trace_traffic_10m.json")
@@ -517,6 +527,15 @@ def main():
                 traffic_src = f"profiles/{os.path.basename(tpath)} ({tj.get('source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command')})"
             except Exception:
                 traffic = None
+        # utilisation of the per-CU vector-memory address path (TA) and the L1 hit rate, from the committed PMC pass of this
+        # command (tools/collect.sh run <round> pmc -> tools/pmc_l1_json.py): attached to the exact workload only
+        l1_pmc = None
+        lpath = os.path.join(ROOT, "profiles", "trace_l1_pmc.json" if G == 708 else "trace_l1_pmc_10m.json")
+        if os.path.exists(lpath) and world == 1 and cam == "a" and (W, H, args.spp) == (1920, 1080, 1) and G in (708, 2237) and args.type == "bottom-up":
+            try:
+                l1_pmc = json.load(open(lpath))
+            except Exception:
+                l1_pmc = None
         roof = {
             # what bounds trace_kernel: the per-CU vector-memory (TA -> L1) path, not HBM (the 128 MB BVH is cache
             # resident).  achieved = algorithmic node + leaf + frame bytes of one launch / the launch's duration ALONE
@@ -525,21 +544,19 @@ def main():
             "unit": "GB/s", "frac": round(serial_l1 / L1_PEAK_GBS, 4),
             "peak_formula": "256 CUs x 64 B/clk x 2.4 GHz (vector L1 data path) -- a NOMINAL figure: MI355X_MICROARCH.md does not "
                             "state it; the measured ceilings of this access pattern are in measured_ceilings",
-            "measured_ceilings": {"divergent_16B_gather_this_repo_GBps": round(GATHER_CEILING_GBS, 1),
-                                  "divergent_16B_gather_source": "tools/ta_microbench.hip, profiles/r02_ta_microbench.txt (0.69 clk per lane request)",
-                                  "l2_served_row_gather_guide_GBps": [16800, 18800],
-                                  "l2_served_row_gather_source": "MI355X_MICROARCH.md, 'Indexed rows: gather into LDS' (2,048 rows shared by every workgroup)",
-                                  "frac_of_divergent_gather": round(serial_l1 / GATHER_CEILING_GBS, 4),
-                                  "frac_of_guide_l2_gather_low": round(serial_l1 / 16800.0, 4)},
+            "reference_rates": {"fully_divergent_16B_gather_GBps": round(GATHER_CEILING_GBS, 1),
+                                "fully_divergent_16B_gather_is": "tools/ta_microbench.hip, profiles/r02_ta_microbench.txt: 0.69 clk per lane request when "
+                                                                 "NO two lanes of a quad agree.  A rate, NOT an upper bound: lanes of a quad that visit the "
+                                                                 "same node share one request (config 5 and camera-coherent frames exceed it)",
+                                "achieved_over_fully_divergent": round(serial_l1 / GATHER_CEILING_GBS, 4),
+                                "l2_served_row_gather_guide_GBps": [16800, 18800],
+                                "l2_served_row_gather_source": "MI355X_MICROARCH.md, 'Indexed rows: gather into LDS' (2,048 rows shared by every workgroup)",
+                                "achieved_over_guide_l2_gather_low": round(serial_l1 / 16800.0, 4)},
+            "address_path_utilisation": l1_pmc,
             "algorithmic_bytes_per_launch": alg_bytes, "formula": "32*sum(box_tests) + 64*sum(tri_tests) + 4*W*rows",
             "kernel_ms": round(serial_ms, 4),
             "kernel_ms_is": f"median of 22 serial launches of this rank's part, HIP events on the launch stream "
                             f"(trace_kernel<{iso_rt}>: same rays and tests as the timed region's trace_kernel<{args.render_type}>)",
-            "divergent_gather_ceiling": {"peak": round(GATHER_CEILING_GBS, 1), "unit": "GB/s",
-                                         "frac": round(serial_l1 / GATHER_CEILING_GBS, 4),
-                                         "is": "16-byte-per-lane loads whose quads disagree cost 0.69 cycles per lane (measured, "
-                                               "profiles/r02_ta_microbench.txt); lanes of a quad that visit the same node share one "
-                                               "request, which is how achieved can approach or pass this line"},
             "algorithmic_over_hbm_peak": round(serial_l1 / HBM_PEAK_GBS, 4),
             "algorithmic_over_hbm_peak_is": "> 1 means cache reuse: these bytes cannot all have come from HBM",
             "traffic": traffic, "traffic_source": traffic_src,
@@ -562,6 +579,9 @@ def main():
             "inflight": S,
             "serial_mrays": round(rays / (serial_ms_max * 1e-3) / 1e6, 2),
             "serial_ms_per_frame": round(serial_ms_max, 4),
+            "counters_in_timed_region": True,
+            "counters_is": "every timed and every serial launch resets and passes the num_tests buffer, as the reference's Trace() does "
+                           "(main.cu:153-157, Tracer.cu:503)",
             "serial_is": "one launch at a time (the reference's frame loop): median of 22 event-timed launches"
                          + ("; slowest rank's part, gather not included" if world > 1 else ""),
             "config": {"workload": f"grid_mesh(G={G}, seed=1) = {n} triangles, {W}x{H}, {args.spp} spp, camera "

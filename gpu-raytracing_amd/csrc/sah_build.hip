@@ -31,6 +31,9 @@
 #include "rt_device.hpp"
 #include "rt_launch.hpp"
 #include "rt_pairing.hpp"
+#ifdef RT_SORT_TUNING
+#include <cstdlib>
+#endif
 
 namespace rt {
 
@@ -1328,6 +1331,7 @@ __device__ __forceinline__ void sah_small_task(const SahArgs& a, SmallSmem& S, u
 // the stack stays below log2 of the task size) and queue the small ones for sah_small_kernel, which runs after this
 // kernel.  Node slots are a function of the split position, so the order tasks are processed in does not matter.
 constexpr uint32_t kFinThreads = 256, kFinStack = 64, kFinGrid = 1024;
+constexpr uint32_t kSahLevelMargin = 3;   // level launches beyond log2(items per cell / kSahSmall)
 
 __global__ __launch_bounds__(kFinThreads) void sah_finish_kernel(SahArgs a, uint32_t lvl)
 {
@@ -1616,8 +1620,11 @@ hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, boo
     // balanced, plus a margin.  The number of launches is FIXED by n: kernels of a level nobody reaches return at once
     // (level_count[lvl] == 0), and whatever is still alive after the last level is finished by sah_finish_kernel, one
     // workgroup per task.  Nothing is read back: the build is a sequence of asynchronous launches.
-    uint32_t batch = 3;
+    uint32_t batch = kSahLevelMargin;
     for (uint32_t per_cell = a.B / kSahCells; per_cell > kSahSmall; per_cell >>= 1) batch++;
+#ifdef RT_SORT_TUNING
+    if (const char* e = getenv("RT_SAH_BATCH_DELTA")) { const int b = (int)batch + atoi(e); batch = b < 0 ? 0u : (uint32_t)b; }   // tools/sah_loop.py sweeps
+#endif
     constexpr uint32_t kSmallGrid = 32768 / kSmallWaves;
     for (uint32_t i = 0; i < batch && lvl + 1 < kSahMaxLevels; i++, lvl++) {
         sah_bin_kernel<<<chunks, 256, 0, st>>>(a, lvl);

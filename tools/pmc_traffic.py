@@ -35,7 +35,7 @@ rec = {
     "workload": "grid_mesh(708,1), 1920x1080, camera A, kDepth, 1 spp, LBVH (python3 bench.py --inflight 1 --steps 3 --warmup 1 --no-extras --no-cpu-baseline)",
     "FETCH_SIZE_KB_raw_median": fetch_kb, "WRITE_SIZE_KB_raw_median": write_kb, "launches_sampled": [nf, nw],
     "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B for 16-B/lane loads -> x2 (MI355X_MICROARCH.md, HBM); "
-                  "WRITE_SIZE exact; separate --pmc passes (tools/pmc_trace.sh)",
+                  "WRITE_SIZE exact; separate --pmc passes (tools/collect.sh, pmc section)",
     "hbm_bytes_per_launch": int(round((2.0 * fetch_kb + write_kb) * 1024)),
     "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, {label}".strip(", "),
 }
