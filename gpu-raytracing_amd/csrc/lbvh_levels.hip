@@ -417,8 +417,56 @@ static_assert(LeafCfg::oLock % 2 == 0 && LeafCfg::oStage % 4 == 0, "64-bit lock 
 static_assert(kLeafCap <= 512, "a lock word packs two 9-bit leaf positions");
 constexpr unsigned long long kLock64Empty = ~0ull;
 
+// What a thread fetches for its leaf of a block, kept in registers until the block's turn: the sorted index, the triangle
+// it names and the Morton codes on both sides of the boundaries it owns (all issued before anything waits).  Separate from
+// the pass so that a workgroup can fetch for a second block while it works on the first (RT_LEAF_BLOCKS=2, see the kernel).
+struct LeafFetch {
+    uint32_t sv, src;
+    float v[9];
+    uint32_t c0, c1, e0, e1;   // codes[g], codes[g + 1] of boundary tid; thread 0: also of boundary kLeafCap
+};
+// step 1: the sorted index and the codes (independent loads)
+__device__ __forceinline__ void leaf_fetch_index(const LevelArgs& a, uint32_t n, uint32_t B0, uint32_t S, LeafFetch& f)
+{
+    const uint32_t tid = threadIdx.x;
+    f.sv = f.src = 0u;
+    f.c0 = f.c1 = f.e0 = f.e1 = 0u;
+    if (tid < S) f.sv = a.sorted_idx[B0 + tid];
+    if (tid <= S) {
+        const int g = (int)B0 + (int)tid - 1;
+        if (g >= 0 && (uint32_t)(g + 1) < n) { f.c0 = a.codes[g]; f.c1 = a.codes[g + 1]; }
+    }
+    if (tid == 0 && S == LeafCfg::CAP) {
+        const int g = (int)B0 + (int)LeafCfg::CAP - 1;
+        if ((uint32_t)(g + 1) < n) { f.e0 = a.codes[g]; f.e1 = a.codes[g + 1]; }
+    }
+}
+// step 2: the triangle the index names (GenerateTriangles, BottomUpBuilder.cu:287-312, fused)
+__device__ __forceinline__ void leaf_fetch_triangle(const LevelArgs& a, uint32_t S, LeafFetch& f)
+{
+#pragma unroll
+    for (int k = 0; k < 9; k++) f.v[k] = 0.0f;
+    if (threadIdx.x < S) {
+        f.src = f.sv & 0x7FFFFFFFu;
+        // the gather address comes from memory: never past the triangle array (a quad leaf also reads triangle src + 1)
+        if (f.src + (f.sv >> 31) >= a.n) {
+            atomicOr(a.status, kErrSortedIndex);
+            f.sv = f.src = 0u;
+        }
+        load_tri9(a.tris + (size_t)f.src * 9, f.v);   // 36 bytes at a 4-byte-aligned address: 2 x 16-byte loads + 1 dword
+    }
+}
+// cpl of the adjacent keys g, g + 1 from their codes (delta_adjacent with the loads done by leaf_fetch_index)
+__device__ __forceinline__ int delta_from_codes(uint32_t c0, uint32_t c1, int g, uint32_t n)
+{
+    if (g < 0 || (uint32_t)(g + 1) >= n) return -1;
+    return c0 == c1 ? 32 + __clz((uint32_t)g ^ (uint32_t)(g + 1)) : __clz(c0 ^ c1);
+}
+
+// Every barrier of the pass orders LDS only (lds_barrier: threads meet through LDS; what goes to global memory is
+// write-only here): a __syncthreads() would also drain the vector-memory counter, i.e. wait for the OTHER block's gather.
 __device__ __forceinline__ void leaf_pass(const LevelArgs& a, uint32_t* smem, uint32_t n, uint32_t B0, uint32_t S,
-                                          uint32_t* out_cnt, uint32_t* out_rec)
+                                          uint32_t* out_cnt, uint32_t* out_rec, const LeafFetch& F)
 {
     using C = LeafCfg;
     constexpr uint32_t NT = C::NT;
@@ -436,26 +484,17 @@ __device__ __forceinline__ void leaf_pass(const LevelArgs& a, uint32_t* smem, ui
     static_assert(C::CAP == NT, "one leaf per thread");
     const uint32_t s0 = tid, i = B0 + s0;
     const bool act = s0 < S;
-    // The block's loads are issued back to back -- sorted index, then the triangle it names, then the codes for the deltas --
-    // and nothing waits for the deltas before the climb: one exposed round trip less per workgroup than deltas, barrier,
-    // index, triangle.
-    uint32_t sv = 0, src = 0;
-    float v[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    if (act) {
-        // GenerateTriangles (BottomUpBuilder.cu:287-312) fused: gather the triangle, emit the 64-byte leaf in sorted order
-        // (ids defined), keep its box in registers.
-        sv = a.sorted_idx[i];
-        src = sv & 0x7FFFFFFFu;
-        // the gather address comes from memory: never past the triangle array (a quad leaf also reads triangle src + 1)
-        if (src + (sv >> 31) >= a.n) {
-            atomicOr(a.status, kErrSortedIndex);
-            sv = src = 0u;
-        }
-        load_tri9(a.tris + (size_t)src * 9, v);   // 36 bytes at a 4-byte-aligned address: 2 x 16-byte loads + 1 dword
+    const uint32_t sv = F.sv, src = F.src;
+    float v[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) v[k] = F.v[k];
+    if (tid <= S) {
+        lock[tid] = kLock64Empty;
+        dl[tid] = delta_from_codes(F.c0, F.c1, (int)B0 + (int)tid - 1, n);
     }
-    for (uint32_t b = tid; b <= S; b += NT) {
-        lock[b] = kLock64Empty;
-        dl[b] = delta_adjacent(a.codes, (int)B0 + (int)b - 1, n);
+    if (tid == 0 && S == C::CAP) {
+        lock[C::CAP] = kLock64Empty;
+        dl[C::CAP] = delta_from_codes(F.e0, F.e1, (int)B0 + (int)C::CAP - 1, n);
     }
     RT_STAMP(0, 1);
 
@@ -505,7 +544,7 @@ __device__ __forceinline__ void leaf_pass(const LevelArgs& a, uint32_t* smem, ui
         // before the build is over, and what a default-policy store leaves behind in the Infinity Cache is written back
         // during the NEXT kernel that streams (scene_aabb of the following build: 100 -> 60 us at 10M).  nt on the strided
         // per-thread stores was the opposite: 838 us (profiles/r03_leaf_store_experiments.txt).
-        __syncthreads();
+        lds_barrier();
         RT_STAMP(0, 5);
         const uint4* st4 = reinterpret_cast<const uint4*>(stage);
         uint4* dst = reinterpret_cast<uint4*>(a.leaves + B0);
@@ -514,7 +553,7 @@ __device__ __forceinline__ void leaf_pass(const LevelArgs& a, uint32_t* smem, ui
             const uint32_t c = tid + k * NT;
             if ((c >> 2) < S) store_stream(dst + c, st4[c]);
         }
-        __syncthreads();   // the climb reuses the staging area
+        lds_barrier();   // the climb reuses the staging area
         RT_STAMP(0, 6);
     }
     if (act) {
@@ -600,7 +639,7 @@ __device__ __forceinline__ void leaf_pass(const LevelArgs& a, uint32_t* smem, ui
             nw[11] = ((cc & 2u) ? 2u : 1u) << 29;
         }
     }
-    __syncthreads();
+    lds_barrier();
     RT_STAMP(0, 2);
 
     {
@@ -630,7 +669,7 @@ __device__ __forceinline__ void leaf_pass(const LevelArgs& a, uint32_t* smem, ui
         mine += ((uint32_t)L < kLockDone) ? 1u : 0u;
     }
     uint32_t total;
-    uint32_t pos = block_excl_scan_u32<NT>(mine, ws, &total);
+    uint32_t pos = block_excl_scan_lds<NT>(mine, ws, &total);
 #pragma unroll
     for (uint32_t j = 0; j < C::PER; j++) {
         const uint32_t rg = (uint32_t)words[j];
@@ -651,6 +690,7 @@ __device__ __forceinline__ void leaf_pass(const LevelArgs& a, uint32_t* smem, ui
         store_sc1(out_cnt, min(total, kMaxOpen));
         if (total > kMaxOpen) atomicOr(a.status, kErrOpenOverflow);  // cannot happen: <= 2 * depth(62) open roots
     }
+    lds_barrier();   // the workgroup's second block reuses the LDS
     RT_STAMP(0, 4);
 }
 
@@ -949,15 +989,38 @@ __device__ __forceinline__ void table_pass(const LevelArgs& a, uint32_t* smem, u
     RT_STAMP(1, so + 4);
 }
 
-// ---- level 0: one 512-thread workgroup per 512 leaves (grids are sized for the largest possible n)
+// ---- level 0: one 512-thread workgroup per block of 512 leaves (grids are sized for the largest possible n).
+// kLeafBlocksPerWg = 2 (a workgroup takes two consecutive blocks and issues the second block's gather before it works on the
+// first: one generation of 980 workgroups at 1M triangles instead of two uneven ones of 1959) was built and measured in
+// round 4: 52.0 vs 47.5 us at 1M, 491 vs 470 us at 10M -- the CU works on four blocks at a time either way, and
+// independent workgroups drift apart (one climbs in LDS while its neighbour waits for memory) where paired blocks march
+// in step.  Kept as a compile-time arm (-DRT_LEAF_BLOCKS=2).
+#ifndef RT_LEAF_BLOCKS
+#define RT_LEAF_BLOCKS 1
+#endif
+constexpr uint32_t kLeafBlocksPerWg = RT_LEAF_BLOCKS;
 __global__ __launch_bounds__(kLeafThreads, 4) void lbvh_leaf_kernel(LevelArgs a)   // four workgroups per CU: 32 waves
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t n = a.n_dev ? *a.n_dev : a.n;
-    const uint32_t blk = blockIdx.x;
-    const uint32_t B0 = blk * kLeafCap;
-    const uint32_t S = B0 < n ? min(kLeafCap, n - B0) : 0u;
-    leaf_pass(a, smem, n, B0, S, a.cnt[0] + blk, a.rec[0] + (size_t)blk * kMaxOpen * kRecDwords);
+    const uint32_t blkA = blockIdx.x * kLeafBlocksPerWg, blkB = blkA + 1;
+    const uint32_t A0 = blkA * kLeafCap, B0 = blkB * kLeafCap;
+    const uint32_t SA = A0 < n ? min(kLeafCap, n - A0) : 0u;
+    LeafFetch FA;
+    leaf_fetch_index(a, n, A0, SA, FA);
+    if (kLeafBlocksPerWg == 2) {
+        const uint32_t SB = (blkB < a.blocks[0] && B0 < n) ? min(kLeafCap, n - B0) : 0u;
+        LeafFetch FB;
+        leaf_fetch_index(a, n, B0, SB, FB);
+        leaf_fetch_triangle(a, SA, FA);
+        leaf_fetch_triangle(a, SB, FB);
+        leaf_pass(a, smem, n, A0, SA, a.cnt[0] + blkA, a.rec[0] + (size_t)blkA * kMaxOpen * kRecDwords, FA);
+        if (blkB < a.blocks[0])
+            leaf_pass(a, smem, n, B0, SB, a.cnt[0] + blkB, a.rec[0] + (size_t)blkB * kMaxOpen * kRecDwords, FB);
+    } else {
+        leaf_fetch_triangle(a, SA, FA);
+        leaf_pass(a, smem, n, A0, SA, a.cnt[0] + blkA, a.rec[0] + (size_t)blkA * kMaxOpen * kRecDwords, FA);
+    }
 }
 
 // ---- all upper levels in one launch: one workgroup per level-1 block; the workgroup that completes the inputs of a
@@ -1158,7 +1221,7 @@ hipError_t launch_lbvh_levels(const rt_triangle* tris, const uint32_t* codes, co
         }
         // the arrival counters must be zero: the caller's init kernel clears them (rt_run_bottom_up_build), see
         // lbvh_arrive_region()
-        lbvh_leaf_kernel<<<p.blocks[0], kLeafThreads, LeafCfg::kBytes, st>>>(a);
+        lbvh_leaf_kernel<<<(p.blocks[0] + kLeafBlocksPerWg - 1) / kLeafBlocksPerWg, kLeafThreads, LeafCfg::kBytes, st>>>(a);
         if (p.num_levels > 1) lbvh_upper_kernel<<<p.blocks[1], 1024, kUpperLds, st>>>(a);
     }
     if (n < 2 || n_dev) lbvh_tiny_kernel<<<1, 64, 0, st>>>(leaves, nodes, n, n_dev);

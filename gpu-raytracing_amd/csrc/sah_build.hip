@@ -1331,7 +1331,11 @@ __device__ __forceinline__ void sah_small_task(const SahArgs& a, SmallSmem& S, u
 // the stack stays below log2 of the task size) and queue the small ones for sah_small_kernel, which runs after this
 // kernel.  Node slots are a function of the split position, so the order tasks are processed in does not matter.
 constexpr uint32_t kFinThreads = 256, kFinStack = 64, kFinGrid = 1024;
-constexpr uint32_t kSahLevelMargin = 3;   // level launches beyond log2(items per cell / kSahSmall)
+// level launches beyond log2(items per cell / kSahSmall).  Measured (tools/sah_loop.py, RT_SAH_BATCH_DELTA on the tuning
+// library, profiles/r04_sah_batch_sweep.txt): 1M grid 0.648 / 0.645 / 0.771 / 1.35 ms for margins 3 / 2 / 1 / 0, 10M 5.43 / 5.39 /
+// 5.41 / 11.6 -- a level the whole GPU sweeps costs 34 us at 1M; the same tasks through the straggler kernel (one workgroup
+// each, plane selection by one thread) cost four times that.  The straggler kernel is the safety net, not the plan.
+constexpr uint32_t kSahLevelMargin = 2;
 
 __global__ __launch_bounds__(kFinThreads) void sah_finish_kernel(SahArgs a, uint32_t lvl)
 {

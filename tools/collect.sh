@@ -21,7 +21,7 @@ if [ "$MODE" = run ]; then
   O=gpurun_out/$R; mkdir -p $O
   prof() { rocprofv3 --kernel-trace --stats --output-format csv -d $O/$1 -- "${@:2}" > $O/$1.log 2>&1 && python3 tools/kstats.py $O/$1 > $O/$1_kernel_stats.txt; }
   B1="--inflight 1 --steps 3 --warmup 1 --no-extras --no-cpu-baseline"   # one launch at a time: clean per-launch counters
-  pmc() { rocprofv3 --kernel-trace --pmc ${@:3} --kernel-include-regex trace_kernel --output-format csv -d $1 -- python3 bench.py $B1 $2 > $1.log 2>&1 || echo "pmc pass $1 failed"; }
+  pmc() { mkdir -p $(dirname $1); rocprofv3 --kernel-trace --pmc ${@:3} --kernel-include-regex trace_kernel --output-format csv -d $1 -- python3 bench.py $B1 $2 > $1.log 2>&1 || echo "pmc pass $1 failed"; }
   pmcset() {   # $1 = output dir prefix, $2 = extra bench arguments
     pmc $1/a "$2" SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
     pmc $1/c "$2" TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum
