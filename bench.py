@@ -242,11 +242,13 @@ def main():
 
     def trace_band(frame, cam_key, render_type, counters=None, rows=None):
         rt.Trace(inp.triangles_out, inp.nodes_out, frame, (W, H), cam_dev[cam_key], ROOT_IDX, ROOT_CNT,
-                 render_type=render_type, counters=counters, rows=rows if rows is not None else (y0, y1), spp=args.spp)
+                 render_type=render_type, counters=counters, rows=rows if rows is not None else (y0, y1), spp=args.spp,
+                 num_primitives=n)
 
     def trace_strips(compact, cam_key, render_type, counters=None):
         rt.Trace(inp.triangles_out, inp.nodes_out, compact, (W, H), cam_dev[cam_key], ROOT_IDX, ROOT_CNT,
-                 render_type=render_type, counters=counters, spp=args.spp, strips=(sharding.STRIP_ROWS, rank, world))
+                 render_type=render_type, counters=counters, spp=args.spp, strips=(sharding.STRIP_ROWS, rank, world),
+                 num_primitives=n)
 
     # ---- partition (N > 1): measure every rank's band (serial launches, events), share the costs, choose
     scratch_frame = torch.zeros(H * W * 4, dtype=torch.uint8, device="cuda")

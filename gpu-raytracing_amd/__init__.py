@@ -324,17 +324,20 @@ class DeviceTextures:
 
 def Trace(triangles, nodes, rgba8, dims, camera, root: int, count: int, *, render_type: int = kDepth,
           attributes=None, materials=None, num_materials: int = 0, light=(0.0, 0.0, 0.0), counters=None,
-          rows=None, spp: int = 1, stream=None, textures: Optional[DeviceTextures] = None, strips=None) -> None:
+          rows=None, spp: int = 1, stream=None, textures: Optional[DeviceTextures] = None, strips=None,
+          num_primitives: int = 0) -> None:
     """main.cu:125-192 Trace(): `camera` is a 64-byte DEVICE buffer, `rgba8` a w*h*4-byte device buffer
     (the reference writes a GL surface; row 0 first).  rows=(y0, y1) restricts to a row band (multi-GPU tiling);
-    strips=(strip_rows, first, stride) renders interleaved strips into a COMPACT buffer (rt_trace_strips)."""
+    strips=(strip_rows, first, stride) renders interleaved strips into a COMPACT buffer (rt_trace_strips).
+    num_primitives: DeviceScene::num_attributes (main.cu:166 sets it to the triangle count; 0 = unknown) -- the library
+    reads it as the scene size when it picks the tracer instantiation (pair prefetch from 8M primitives on)."""
     w, h = int(dims[0]), int(dims[1])
     y0, y1 = (0, h) if rows is None else (int(rows[0]), int(rows[1]))
     if strips is not None:
         a = _Accel(_ptr(triangles), _ptr(nodes), root, count)
         s = _Scene(_ptr(attributes), _ptr(materials), _ptr(textures.table) if textures is not None else 0, _ptr(camera),
                    (ctypes.c_float * 3)(*[float(x) for x in light]),
-                   0, num_materials, textures.count if textures is not None else 0)
+                   int(num_primitives), num_materials, textures.count if textures is not None else 0)
         _check(lib().rt_trace_strips(ctypes.byref(a), ctypes.byref(s), _ptr(counters), render_type, _ptr(rgba8), w, h,
                                      int(strips[0]), int(strips[1]), int(strips[2]), spp, _stream_ptr(stream)),
                "rt_trace_strips")
@@ -342,7 +345,7 @@ def Trace(triangles, nodes, rgba8, dims, camera, root: int, count: int, *, rende
     a = _Accel(_ptr(triangles), _ptr(nodes), root, count)
     s = _Scene(_ptr(attributes), _ptr(materials), _ptr(textures.table) if textures is not None else 0, _ptr(camera),
                (ctypes.c_float * 3)(*[float(x) for x in light]),
-               0, num_materials, textures.count if textures is not None else 0)
+               int(num_primitives), num_materials, textures.count if textures is not None else 0)
     _check(lib().rt_trace(ctypes.byref(a), ctypes.byref(s), _ptr(counters), render_type, _ptr(rgba8), w, h, y0, y1,
                           spp, _stream_ptr(stream)), "rt_trace")
 

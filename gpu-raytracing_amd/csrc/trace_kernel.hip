@@ -41,6 +41,7 @@ namespace rt {
 
 constexpr int kStackLds = 16;    // LDS-resident stack entries per lane (bench scenes peak at 10)
 constexpr int kStackMax = 64;    // reference stack size (Tracer.cu:314)
+constexpr uint32_t kPrefetchMinPrims = 8u << 20;   // scenes from here on take the pair-prefetch instantiation (see trace_kernel)
 #ifndef RT_TRACE_WAVES
 #define RT_TRACE_WAVES 4
 #endif
@@ -136,6 +137,9 @@ struct Trav {
     uint32_t e1;        // child : 29 | count : 3
     uint32_t t1;        // type, 0 = none / absent
     uint32_t box_tests, tri_tests;
+    // PF instantiations only (scenes whose tree does not fit the caches, see launch_trace): the next pair's four 16-byte
+    // loads, issued as soon as advance() has picked it -- before the wave's next vote -- and carried in registers
+    uint4 pf0, pf1, pf2, pf3;
 
     __device__ __forceinline__ void push(uint32_t e)
     {
@@ -193,8 +197,21 @@ __device__ __forceinline__ void slab(const uint4& a, const uint4& b, const Ray& 
     back = fminf(fminf(fmaxf(t1.x, t2.x), fmaxf(t1.y, t2.y)), fmaxf(t1z, t2z));
 }
 
+template <bool PF>
+__device__ __forceinline__ void prefetch_pair(const TraceParams& p, Trav& t)
+{
+    if constexpr (PF) {
+        if (t.phase == PH_STEP) {
+            const uint4* np = reinterpret_cast<const uint4*>(p.nodes + (t.cur & kIndexMask));
+            const int o1 = (t.cur >> 29) > 1 ? 2 : 0;
+            t.pf0 = np[0]; t.pf1 = np[1]; t.pf2 = np[o1]; t.pf3 = np[o1 + 1];
+        }
+    }
+}
+
 // One box step of a lane (Tracer.cu:323-352 for one pair): both slots of the current pair are loaded and both slabs
 // computed before the ordered tmax compares; a leaf in the first slot parks the lane with the second slot's slab kept.
+template <bool PF>
 __device__ __forceinline__ void box_step(const TraceParams& p, const Ray& r, Trav& t)
 {
     const uint32_t cnt = t.cur >> 29;
@@ -205,7 +222,9 @@ __device__ __forceinline__ void box_step(const TraceParams& p, const Ray& r, Tra
 #endif
     const bool two = cnt > 1;
     const int o1 = two ? 2 : 0;  // all four loads issue together; a lone slot is simply read twice
-    const uint4 a0 = np[0], b0 = np[1], a1 = np[o1], b1 = np[o1 + 1];
+    uint4 a0, b0, a1, b1;
+    if constexpr (PF) { a0 = t.pf0; b0 = t.pf1; a1 = t.pf2; b1 = t.pf3; }
+    else { a0 = np[0]; b0 = np[1]; a1 = np[o1]; b1 = np[o1 + 1]; }
     float f0, k0;
     slab(a0, b0, r, f0, k0);
     slab(a1, b1, r, t.f1, t.k1);
@@ -221,12 +240,13 @@ __device__ __forceinline__ void box_step(const TraceParams& p, const Ray& r, Tra
     if (leaf0) { t.leaf = e0; t.phase = PH_LEAF0; }
     else {
         t.second_slot(r.tmin, r.tmax);
-        if (t.phase == PH_STEP) t.advance();
+        if (t.phase == PH_STEP) { t.advance(); prefetch_pair<PF>(p, t); }
     }
 }
 
 // Tracer.cu:308-374, restructured as described in the file header.  Returns tri_hit.
 // steps[0] / steps[1] count the wave's box-phase / leaf-phase iterations (profiling aid).
+template <bool PF>
 __device__ __forceinline__ bool trace_ray(const TraceParams& p, Ray& r, Hit& h, Trav& t, bool active, uint32_t* steps)
 {
     t.sp = 0;
@@ -240,6 +260,7 @@ __device__ __forceinline__ bool trace_ray(const TraceParams& p, Ray& r, Hit& h, 
     t.e1 = 0;
     t.f1 = t.k1 = 0.0f;
     t.leaf = 0;
+    prefetch_pair<PF>(p, t);
     bool tri_hit = false;
     uint32_t nbox = 0, nleaf = 0;
 
@@ -251,9 +272,9 @@ __device__ __forceinline__ bool trace_ray(const TraceParams& p, Ray& r, Hit& h, 
             parked = __builtin_amdgcn_ballot_w64((t.phase - 1u) < 2u);
             if (stepping == 0 || __popcll(stepping) * p.park_den < __popcll(parked) * p.park_num) break;
             nbox += 2;   // two box steps per vote (below)
-            if (t.phase == PH_STEP) box_step(p, r, t);
+            if (t.phase == PH_STEP) box_step<PF>(p, r, t);
             // second step under the same vote: halves the per-step loop overhead (ballots, branch, copies)
-            if (t.phase == PH_STEP) box_step(p, r, t);
+            if (t.phase == PH_STEP) box_step<PF>(p, r, t);
         }
         if ((stepping | parked) == 0) break;
         // ---------------------------------------------------- leaf phase (Tracer.cu:333-337, 293-306)
@@ -278,7 +299,7 @@ __device__ __forceinline__ bool trace_ray(const TraceParams& p, Ray& r, Hit& h, 
             const bool was_first = t.phase == PH_LEAF0;
             t.phase = PH_STEP;
             if (was_first) t.second_slot(r.tmin, r.tmax);
-            if (t.phase == PH_STEP) t.advance();
+            if (t.phase == PH_STEP) { t.advance(); prefetch_pair<PF>(p, t); }
         }
     }
 #ifndef RT_TRACE_NO_STEPS
@@ -436,7 +457,7 @@ constexpr bool render_uses_surface(int r) { return r == RT_RENDER_LODS || r == R
 // one sample of one pixel -> float colour 0..255 per channel + alpha (TraceRays body, Tracer.cu:482-593).
 // Every lane of the wave calls this (inactive lanes trace nothing) because trace_ray votes with ballots; the shadow
 // ray of kTextureLitShadows is a second wave-level traversal over the lanes that hit something.
-template <int RENDER>
+template <int RENDER, bool PF>
 __device__ __forceinline__ void shade_sample(const TraceParams& p, const rt_camera& cam, uint32_t x, uint32_t y,
                                              float ox, float oy, Trav& t, bool active, uint32_t& box_acc,
                                              uint32_t& tri_acc, uint32_t* steps, float& R, float& G, float& B, float& A)
@@ -455,7 +476,7 @@ __device__ __forceinline__ void shade_sample(const TraceParams& p, const rt_came
     r.tmin = 0.00001f;
     r.tmax = max_depth;
     Hit h = {0u, 0u, 0.f, 0.f};
-    const bool hit = trace_ray(p, r, h, t, active, steps);
+    const bool hit = trace_ray<PF>(p, r, h, t, active, steps);
     const uint32_t box_tests = t.box_tests, tri_tests = t.tri_tests;
     box_acc += box_tests;
     tri_acc += tri_tests;
@@ -559,7 +580,7 @@ __device__ __forceinline__ void shade_sample(const TraceParams& p, const rt_came
         sr.tmin = 0.001f;
         sr.tmax = to_light;
         Hit sh = {0u, 0u, 0.f, 0.f};
-        shadowed = trace_ray(p, sr, sh, t, lit, steps);   // its test counts are not reported (shadow_stats, :451)
+        shadowed = trace_ray<PF>(p, sr, sh, t, lit, steps);   // its test counts are not reported (shadow_stats, :451)
     }
     if (!lit) return;
     const float w0 = 1 - h.bu - h.bv;
@@ -608,7 +629,13 @@ __device__ __forceinline__ void shade_sample(const TraceParams& p, const rt_came
     B = clampf(cb, 0.0f, 1.0f) * 255;
 }
 
-template <int RENDER>
+// PF (pair prefetch): for trees that do not fit the caches.  On the 10M-triangle scene (1.28 GB of nodes + leaves, 5 x the
+// Infinity Cache; L2 hit 94 %) a wave waits for L2 misses, not for the address path: issuing the NEXT pair's loads right
+// after advance() -- one more pair in flight per lane across the wave's vote -- at 96 VGPRs / 5 waves per SIMD is +8 % serial,
+// +16 % with frames in flight on camera A, +6 / +14 % on camera B; on the cache-resident 1M tree the same kernel is 25 % SLOWER
+// (five waves instead of eight feed the address path), at 4.5M -7 % / +6 %; at 64 - 80 VGPRs the sixteen extra registers
+// spill and it is 2 - 5 x slower everywhere (profiles/r04_trace_10m_experiments.txt).  launch_trace picks it by scene size.
+template <int RENDER, bool PF>
 // kDepth / kBoxtests / kTriangleTests end in a one-line colour conversion: they fit 64 VGPRs (8 waves per SIMD); the
 // shading of the other render types would spill there, they keep 72 VGPRs (7 waves)
 // (RT_TRACE_LEAN_EXTRA = 0 and RT_TRACE_NO_STEPS are the compile-time arms of tools/trace_spill_experiment.sh, which priced
@@ -616,7 +643,10 @@ template <int RENDER>
 #ifndef RT_TRACE_LEAN_EXTRA
 #define RT_TRACE_LEAN_EXTRA 1
 #endif
-__global__ __launch_bounds__(kTraceWaves * 64, (RENDER <= 2 || RENDER == kRenderDebugBoxCount) ? RT_TRACE_MIN_WAVES + RT_TRACE_LEAN_EXTRA : RT_TRACE_MIN_WAVES)
+#ifndef RT_TRACE_PF_WAVES
+#define RT_TRACE_PF_WAVES 5
+#endif
+__global__ __launch_bounds__(kTraceWaves * 64, PF ? RT_TRACE_PF_WAVES : ((RENDER <= 2 || RENDER == kRenderDebugBoxCount) ? RT_TRACE_MIN_WAVES + RT_TRACE_LEAN_EXTRA : RT_TRACE_MIN_WAVES))
 void trace_kernel(TraceParams p)
 {
     __shared__ uint32_t stack_lds[kTraceWaves][kStackLds][64];
@@ -668,13 +698,13 @@ void trace_kernel(TraceParams p)
     uint32_t steps[2] = {0u, 0u};
     float R, G, B, A;
     if (p.spp <= 1) {
-        shade_sample<RENDER>(p, cam, x, y, 0.5f, 0.5f, t, active, box_acc, tri_acc, steps, R, G, B, A);
+        shade_sample<RENDER, PF>(p, cam, x, y, 0.5f, 0.5f, t, active, box_acc, tri_acc, steps, R, G, B, A);
     } else {
         float ar = 0, ag = 0, ab = 0, aa = 0;
         const uint32_t side = p.spp == 4 ? 2u : 4u;   // stratified side x side sub-pixel grid (2 x 2 or 4 x 4)
         for (uint32_t s = 0; s < p.spp; s++) {
             const float ox = ((float)(s % side) + 0.5f) / (float)side, oy = ((float)((s / side) % side) + 0.5f) / (float)side;
-            shade_sample<RENDER>(p, cam, x, y, ox, oy, t, active, box_acc, tri_acc, steps, R, G, B, A);
+            shade_sample<RENDER, PF>(p, cam, x, y, ox, oy, t, active, box_acc, tri_acc, steps, R, G, B, A);
             ar += R; ag += G; ab += B; aa += A;
         }
         R = ar / (float)p.spp; G = ag / (float)p.spp; B = ab / (float)p.spp; A = aa / (float)p.spp;
@@ -754,21 +784,26 @@ hipError_t launch_trace(const TraceLaunch& t, hipStream_t st)
 #endif
     const uint32_t blocks = (p.num_tiles + kTraceWaves - 1) / kTraceWaves;
     const dim3 grid(blocks), block(kTraceWaves * 64);
+    // scene size (DeviceScene::num_attributes, filled by the caller as main.cu:166 does; 0 = unknown): a tree of kPrefetchMinPrims
+    // primitives is 1 GB of nodes + leaves, four times the Infinity Cache
+    const bool pf = t.scene.num_attributes >= kPrefetchMinPrims;
+#define RT_TRACE_CASE(R) case R: if (pf) trace_kernel<R, true><<<grid, block, 0, st>>>(p); else trace_kernel<R, false><<<grid, block, 0, st>>>(p); break;
     switch (t.render_type) {
-    case RT_RENDER_DEPTH: trace_kernel<RT_RENDER_DEPTH><<<grid, block, 0, st>>>(p); break;
-    case RT_RENDER_BOXTESTS: trace_kernel<RT_RENDER_BOXTESTS><<<grid, block, 0, st>>>(p); break;
-    case RT_RENDER_TRIANGLE_TESTS: trace_kernel<RT_RENDER_TRIANGLE_TESTS><<<grid, block, 0, st>>>(p); break;
-    case RT_RENDER_MATERIAL_ID: trace_kernel<RT_RENDER_MATERIAL_ID><<<grid, block, 0, st>>>(p); break;
-    case RT_RENDER_DIFFUSE: trace_kernel<RT_RENDER_DIFFUSE><<<grid, block, 0, st>>>(p); break;
-    case RT_RENDER_LODS: trace_kernel<RT_RENDER_LODS><<<grid, block, 0, st>>>(p); break;
-    case RT_RENDER_TEXTURE: trace_kernel<RT_RENDER_TEXTURE><<<grid, block, 0, st>>>(p); break;
-    case RT_RENDER_TEXTURE_LIT: trace_kernel<RT_RENDER_TEXTURE_LIT><<<grid, block, 0, st>>>(p); break;
-    case RT_RENDER_TEXTURE_LIT_SHADOWS: trace_kernel<RT_RENDER_TEXTURE_LIT_SHADOWS><<<grid, block, 0, st>>>(p); break;
+    RT_TRACE_CASE(RT_RENDER_DEPTH)
+    RT_TRACE_CASE(RT_RENDER_BOXTESTS)
+    RT_TRACE_CASE(RT_RENDER_TRIANGLE_TESTS)
+    RT_TRACE_CASE(RT_RENDER_MATERIAL_ID)
+    RT_TRACE_CASE(RT_RENDER_DIFFUSE)
+    RT_TRACE_CASE(RT_RENDER_LODS)
+    RT_TRACE_CASE(RT_RENDER_TEXTURE)
+    RT_TRACE_CASE(RT_RENDER_TEXTURE_LIT)
+    RT_TRACE_CASE(RT_RENDER_TEXTURE_LIT_SHADOWS)
 #ifdef RT_TRACE_TUNING
-    case kRenderDebugBoxCount: trace_kernel<kRenderDebugBoxCount><<<grid, block, 0, st>>>(p); break;
+    case kRenderDebugBoxCount: trace_kernel<kRenderDebugBoxCount, false><<<grid, block, 0, st>>>(p); break;
 #endif
     default: return hipErrorInvalidValue;
     }
+#undef RT_TRACE_CASE
     return hipGetLastError();
 }
 

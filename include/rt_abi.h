@@ -104,7 +104,9 @@ typedef struct rt_scene {
     const rt_texture*    textures;
     const rt_camera*     camera;        /* device pointer, as in the reference (main.cu:151,161) */
     float                light[3];
-    uint32_t             num_attributes, num_materials, num_textures;
+    uint32_t             num_attributes, num_materials, num_textures;   /* num_attributes = number of primitives (main.cu:166); also
+                                                                          the scene-size hint of rt_trace (0 = unknown): from 8M
+                                                                          primitives on the tracer takes its pair-prefetch form */
 } rt_scene;
 
 enum {

@@ -32,7 +32,7 @@ def gpu_build(tris: np.ndarray):
 
 
 def gpu_trace(build, camera, w, h, render_type=0, attributes=None, materials=None, light=(0, 0, 0), rows=None, spp=1,
-              root=0, count=2, textures=None):
+              root=0, count=2, textures=None, num_primitives=0):
     import torch
     inp = build["inp"]
     cam_d = rt.to_device(camera)
@@ -43,7 +43,7 @@ def gpu_trace(build, camera, w, h, render_type=0, attributes=None, materials=Non
     rt.Trace(inp.triangles_out, inp.nodes_out, rgba, (w, h), cam_d, root, count, render_type=render_type,
              attributes=at_d, materials=mt_d, num_materials=0 if materials is None else materials.shape[0],
              light=light, counters=counters, rows=rows, spp=spp,
-             textures=rt.DeviceTextures(textures) if textures is not None else None)
+             textures=rt.DeviceTextures(textures) if textures is not None else None, num_primitives=num_primitives)
     torch.cuda.synchronize()
     return rgba.cpu().numpy().reshape(h, w, 4), counters.cpu().numpy().astype(np.uint64)[:2]
 

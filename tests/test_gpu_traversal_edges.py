@@ -199,3 +199,55 @@ def test_axis_parallel_rays_on_box_planes(rt, scenes, ora, tree):
                 gi, gc = gpu_trace(g, cam, w, h, render_type, root=root, count=count)
                 assert (gc == oc[:2]).all(), f"{tree} {pos} {w}x{h} render {render_type}: counters {gc} vs {oc}"
                 assert (gi == oi).all(), f"{tree} {pos}: {(gi != oi).any(axis=2).sum()} pixels differ"
+
+
+BIG = 10_000_000   # a scene-size hint (DeviceScene::num_attributes) that selects the pair-prefetch instantiations
+
+
+@pytest.mark.parametrize("tree", ["lbvh", "sah"])
+def test_prefetch_instantiation_deep_stack_all_render_types(fractal, scenes, ora, tree):
+    """trace_kernel<RENDER, PF = true> (picked for scenes of >= 8M primitives: the next pair's loads are issued right after
+    advance() and carried in registers across the wave's vote) must walk exactly like the default instantiation: the deep
+    scene, every untextured render type, frames and counters against the oracle."""
+    from helpers import gpu_trace
+    g, o, root, count = fractal[tree]
+    tris = fractal["tris"]
+    n = tris.shape[0]
+    mats = scenes.default_materials(3)
+    at = scenes.flat_attributes(tris, np.arange(n, dtype=np.int32) % 3)
+    kw = dict(attributes=at, materials=mats, light=(-2.0 ** 44, 2.0 ** 45, -2.0 ** 43))
+    for render_type in (0, 1, 2, 3, 5, 8):
+        oi, oc = ora.trace(o["leaves"], o["nodes"], root, count, fractal["cam"], 96, 64, render_type=render_type, **kw)
+        gi, gc = gpu_trace(g, fractal["cam"], 96, 64, render_type, root=root, count=count, num_primitives=BIG, **kw)
+        assert (gc == oc[:2]).all(), f"{tree} render {render_type}: counters {gc} vs {oc}"
+        assert (gi == oi).all(), f"{tree} render {render_type}: {(gi != oi).any(axis=2).sum()} pixels differ"
+
+
+def test_prefetch_instantiation_full_stack_wide_nodes_and_bands(rt, scenes, ora):
+    """The same instantiation on the full-stack scene (dropped pushes), on nodes wider than a pair (the prefetch must take
+    the lone-slot form of a node's last step) and on row bands / 16 spp (ragged tiles, inactive lanes)."""
+    from helpers import gpu_trace
+    tris = scenes.fractal_corner(8000, 3, octaves=140, top_exp=42)
+    o = ora.build_sah(tris)
+    g = _gpu_sah(rt, tris)
+    cam = scenes.diagonal_camera(2.0 ** -10, 2.0 ** 45)
+    oi, oc = ora.trace(o["leaves"], o["nodes"], 0, 1, cam, 33, 25, render_type=1)
+    assert oc[3] > 0
+    gi, gc = gpu_trace(g, cam, 33, 25, 1, root=0, count=1, num_primitives=BIG)
+    assert (gc == oc[:2]).all() and (gi == oi).all()
+    tris = scenes.soup(1500, 5, dup_fraction=0.2, size=0.2)
+    b = ora.build_bvh(tris)
+    lo, hi = ora.ordered_to_float(b["aabb"][:3]), ora.ordered_to_float(b["aabb"][3:])
+    cam = scenes.camera_for_box(lo, hi)
+    for width in (3, 4, 7):
+        nodes, root, count = edge_scenes.collapse_wide(b["nodes"], 0, 2, width, rt.NODE)
+        gw = _upload_tree(rt, nodes, b["leaves"])
+        oi, oc = ora.trace(b["leaves"], nodes, root, count, cam, 160, 100, render_type=1)
+        gi, gc = gpu_trace(gw, cam, 160, 100, 1, root=root, count=count, num_primitives=BIG)
+        assert (gc == oc[:2]).all(), f"width {width}"
+        assert (gi == oi).all()
+    gb = _gpu_bu(rt, tris)
+    for rows, spp in (((13, 50), 1), ((0, 101), 16)):
+        oi, oc = ora.trace(b["leaves"], b["nodes"], 0, 2, cam, 130, 101, render_type=0, rows=rows, spp=spp)
+        gi, gc = gpu_trace(gb, cam, 130, 101, 0, rows=rows, spp=spp, num_primitives=BIG)
+        assert (gc == oc[:2]).all() and (gi[rows[0]:rows[1]] == oi[rows[0]:rows[1]]).all()
