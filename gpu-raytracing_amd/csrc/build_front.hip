@@ -6,7 +6,6 @@
 // issues 6 global atomics per triangle on one 24-byte address).
 #include "rt_device.hpp"
 #include "rt_launch.hpp"
-#include "rt_sort_group.hpp"
 #include "rt_pairing.hpp"
 
 namespace rt {
@@ -22,7 +21,7 @@ namespace rt {
 // tiny initialisations (status words, the level hand-off counters: BuildWrapper.cu:288-303 does such things with six
 // memset / memcpy calls), and every workgroup STORES its partial box at aabb[6 * blockIdx.x] (no atomics, so nothing
 // needs resetting first); the Morton kernels fold the gridDim.x partial boxes.
-struct BuildInit { uint32_t* status; uint32_t n_tris; uint32_t* arrive; uint32_t arrive_words; uint32_t* sort_arrive; };
+struct BuildInit { uint32_t* status; uint32_t n_tris; uint32_t* arrive; uint32_t arrive_words; };
 
 __global__ __launch_bounds__(1024) void scene_aabb_kernel(const float* __restrict__ f, uint64_t nfloats,
                                                           int* __restrict__ aabb, uint32_t nparts, BuildInit init)
@@ -30,7 +29,6 @@ __global__ __launch_bounds__(1024) void scene_aabb_kernel(const float* __restric
     if (init.status && blockIdx.x == 0) {
         if (threadIdx.x < 8) init.status[threadIdx.x] = threadIdx.x == 1 ? init.n_tris : 0u;   // [1] = number of leaves (pairs: overwritten)
         for (uint32_t i = threadIdx.x; i < init.arrive_words; i += 1024) init.arrive[i] = 0u;
-        if (init.sort_arrive && threadIdx.x < kSortMaxGroups) init.sort_arrive[threadIdx.x] = 0u;   // tickets of the sort's grouped scan
     }
     const uint64_t nvec = nfloats >> 2;
     const uint64_t stride = (uint64_t)gridDim.x * 1024;
@@ -196,14 +194,12 @@ template <uint32_t BITS, uint32_t NT, uint32_t TQ>
 __global__ __launch_bounds__(NT) void morton_hist_kernel(uint32_t* __restrict__ codes, uint32_t* __restrict__ values,
                                                           const float* __restrict__ f, const int* __restrict__ aabb,
                                                           uint32_t n, uint32_t nparts, int* __restrict__ aabb_out,
-                                                          uint32_t* hist, uint32_t stride, uint32_t num_tiles,
-                                                          uint32_t* offs, uint32_t* group_total, uint32_t* arrive)   // arrive != null: grouped scan
+                                                          uint32_t* __restrict__ hist, uint32_t stride)
 {
     constexpr uint32_t RADIX = 1u << BITS;
     static_assert(TQ == 1 || TQ == 4, "one dword or one uint4 per digit");
     __shared__ uint32_t h[TQ][RADIX];
     __shared__ int sbox[6];
-    __shared__ uint32_t tail_flag;
     float bmin[3], bmax[3];
     for (uint32_t d = threadIdx.x; d < RADIX * TQ; d += NT) (&h[0][0])[d] = 0;
     fold_scene_box(aabb, nparts, sbox, bmin, bmax);   // (its barriers also order the zeroing of h)
@@ -246,11 +242,6 @@ __global__ __launch_bounds__(NT) void morton_hist_kernel(uint32_t* __restrict__ 
         }
     }
     __syncthreads();
-    if (TQ == 1 && arrive) {   // few tiles: the sort's first scan is folded in too (rt_sort_group.hpp)
-        for (uint32_t d = threadIdx.x; d < RADIX; d += NT) sort_store_sc1(hist + (size_t)d * stride + tile0, h[0][d]);
-        sort_group_tail<BITS, NT>(hist, offs, group_total, arrive, tile0, num_tiles, stride, &tail_flag);
-        return;
-    }
     for (uint32_t d = threadIdx.x; d < RADIX; d += NT) {
         if (TQ == 4) *reinterpret_cast<uint4*>(hist + (size_t)d * stride + tile0) = make_uint4(h[0][d], h[1 % TQ][d], h[2 % TQ][d], h[3 % TQ][d]);
         else hist[(size_t)d * stride + tile0] = h[0][d];
@@ -397,18 +388,18 @@ hipError_t launch_scene_aabb(const rt_triangle* tris, uint32_t n, int* aabb, hip
 {
     if (n == 0) return hipSuccess;
     scene_aabb_kernel<<<scene_aabb_blocks(n, nparts > 1), 1024, 0, st>>>(reinterpret_cast<const float*>(tris), (uint64_t)n * 9, aabb,
-                                                                        nparts ? nparts : 1u, BuildInit{nullptr, 0, nullptr, 0, nullptr});
+                                                                        nparts ? nparts : 1u, BuildInit{nullptr, 0, nullptr, 0});
     return hipGetLastError();
 }
 
 // the build's first launch: partial boxes stored at aabb_parts[6 * workgroup] (*nparts_out of them) + the initialisations
 hipError_t launch_scene_aabb_build(const rt_triangle* tris, uint32_t n, int* aabb_parts, uint32_t* nparts_out, uint32_t* status,
-                                   uint32_t* arrive, uint32_t arrive_words, uint32_t* sort_arrive, hipStream_t st)
+                                   uint32_t* arrive, uint32_t arrive_words, hipStream_t st)
 {
     const uint32_t blocks = scene_aabb_blocks(n, true);
     *nparts_out = blocks;
     scene_aabb_kernel<<<blocks, 1024, 0, st>>>(reinterpret_cast<const float*>(tris), (uint64_t)n * 9, aabb_parts, blocks,
-                                               BuildInit{status, n, arrive, arrive_words, sort_arrive});
+                                               BuildInit{status, n, arrive, arrive_words});
     return hipGetLastError();
 }
 
@@ -422,27 +413,21 @@ hipError_t launch_morton(uint32_t* codes, uint32_t* values, const rt_triangle* t
 }
 
 hipError_t launch_morton_hist(uint32_t* codes, uint32_t* values, const rt_triangle* tris, const int* aabb, uint32_t n,
-                              hipStream_t st, uint32_t nparts, int* aabb_out, void* sort_scratch, uint32_t bits)
+                              hipStream_t st, uint32_t nparts, int* aabb_out, uint32_t* hist, uint32_t bits)
 {
     if (n == 0) return hipSuccess;
     const uint32_t tiles = sort_num_tiles(n), stride = sort_table_stride(tiles);
     const float* f = reinterpret_cast<const float*>(tris);
     const uint32_t np = nparts ? nparts : 1u;
-    const SortScratch L = sort_scratch_layout(n);
-    char* base = static_cast<char*>(sort_scratch);
-    uint32_t* hist = reinterpret_cast<uint32_t*>(base + L.hist);
-    uint32_t* offs = reinterpret_cast<uint32_t*>(base + L.offs);
-    uint32_t* gtot = reinterpret_cast<uint32_t*>(base + L.group_total);
-    uint32_t* arrive = sort_grouped(tiles) ? reinterpret_cast<uint32_t*>(base + L.arrive) : nullptr;
     // few tiles: 1024 threads per tile (4 triangles each) -- a pass over 245 tiles is one workgroup's chain; many: 256
     // threads per tile (four tiles per workgroup, as the sort's own histogram kernel does, was measured slower here: 83 vs
     // 77 us at 10M -- this kernel is bound by the 36-byte triangle reads, not by its table writes)
     if (sort_upsweep_quads(tiles)) {
-        if (bits == 10) morton_hist_kernel<10, 256, 1><<<tiles, 256, 0, st>>>(codes, values, f, aabb, n, np, aabb_out, hist, stride, tiles, nullptr, nullptr, nullptr);
-        else morton_hist_kernel<8, 256, 1><<<tiles, 256, 0, st>>>(codes, values, f, aabb, n, np, aabb_out, hist, stride, tiles, nullptr, nullptr, nullptr);
+        if (bits == 10) morton_hist_kernel<10, 256, 1><<<tiles, 256, 0, st>>>(codes, values, f, aabb, n, np, aabb_out, hist, stride);
+        else morton_hist_kernel<8, 256, 1><<<tiles, 256, 0, st>>>(codes, values, f, aabb, n, np, aabb_out, hist, stride);
     } else {
-        if (bits == 10) morton_hist_kernel<10, 1024, 1><<<tiles, 1024, 0, st>>>(codes, values, f, aabb, n, np, aabb_out, hist, stride, tiles, offs, gtot, arrive);
-        else morton_hist_kernel<8, 1024, 1><<<tiles, 1024, 0, st>>>(codes, values, f, aabb, n, np, aabb_out, hist, stride, tiles, offs, gtot, arrive);
+        if (bits == 10) morton_hist_kernel<10, 1024, 1><<<tiles, 1024, 0, st>>>(codes, values, f, aabb, n, np, aabb_out, hist, stride);
+        else morton_hist_kernel<8, 1024, 1><<<tiles, 1024, 0, st>>>(codes, values, f, aabb, n, np, aabb_out, hist, stride);
     }
     return hipGetLastError();
 }

@@ -20,7 +20,6 @@
 
 #include "rt_device.hpp"
 #include "rt_launch.hpp"
-#include "rt_sort_group.hpp"
 
 #ifdef RT_SORT_TUNING
 #include <cstdlib>
@@ -74,15 +73,13 @@ __device__ __forceinline__ void hist_add(uint32_t* h, uint32_t d, bool valid, bo
 template <uint32_t BITS, uint32_t NT, uint32_t TQ>
 __global__ __launch_bounds__(NT) void sort_upsweep_kernel(const uint32_t* __restrict__ keys, uint32_t n,
                                                            uint32_t shift, uint32_t num_tiles, uint32_t stride,
-                                                           uint32_t* hist, const uint32_t* n_dev, int vec_ok,
-                                                           uint32_t* offs, uint32_t* group_total, uint32_t* arrive)   // arrive != null: grouped scan
+                                                           uint32_t* __restrict__ hist, const uint32_t* n_dev, int vec_ok)
 {
     constexpr uint32_t RADIX = 1u << BITS;
     constexpr uint32_t ITEMS = kSortTile / NT;
     static_assert(TQ == 1 || TQ == 4, "one dword or one uint4 per digit");
     if (n_dev) n = *n_dev;   // device-side count (--pairs): tiles past it see no valid key and publish zeros
     __shared__ uint32_t h[TQ][RADIX];   // (digit-minor: neighbouring digits on neighbouring banks)
-    __shared__ uint32_t tail_flag;
     for (uint32_t d = threadIdx.x; d < RADIX * TQ; d += NT) (&h[0][0])[d] = 0;
     __syncthreads();
     const uint32_t tile0 = blockIdx.x * TQ;
@@ -126,11 +123,6 @@ __global__ __launch_bounds__(NT) void sort_upsweep_kernel(const uint32_t* __rest
     }
     __syncthreads();
     // no global atomics anywhere in the sort.  (tile0 + TQ <= stride: the padding columns of the last group get zeros)
-    if (TQ == 1 && arrive) {   // few tiles: publish write-through, then the last workgroup of the group scans it (rt_sort_group.hpp)
-        for (uint32_t d = threadIdx.x; d < RADIX; d += NT) sort_store_sc1(hist + (size_t)d * stride + tile0, h[0][d]);
-        sort_group_tail<BITS, NT>(hist, offs, group_total, arrive, tile0, num_tiles, stride, &tail_flag);
-        return;
-    }
     for (uint32_t d = threadIdx.x; d < RADIX; d += NT) {
         if (TQ == 4) *reinterpret_cast<uint4*>(hist + (size_t)d * stride + tile0) = make_uint4(h[0][d], h[1 % TQ][d], h[2 % TQ][d], h[3 % TQ][d]);
         else hist[(size_t)d * stride + tile0] = h[0][d];
@@ -219,18 +211,15 @@ __device__ __forceinline__ buf_t make_buf(const void* p, uint32_t bytes)
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
 
-// GROUPED: the scan was folded into the histogram kernels (rt_sort_group.hpp): `totals` is then an OUTPUT (workgroup 0
-// publishes the digit totals: the SAH build reads its cell sizes there) and the tile's offsets come from sort_group_lookup.
-template <uint32_t BITS, uint32_t NT, bool IDENT, int EXP = 0, bool GROUPED = false>   // EXP != 0: timing experiments of the tuning build (wrong output)
+template <uint32_t BITS, uint32_t NT, bool IDENT, int EXP = 0>   // EXP != 0: timing experiments of the tuning build (wrong output)
 __global__ __launch_bounds__(NT, (NT == 512 && BITS == 8) ? 6 : 4) void sort_downsweep_kernel(const uint32_t* __restrict__ keys_in,
                                                             const uint32_t* __restrict__ vals_in,
                                                             uint32_t* __restrict__ keys_out,
                                                             uint32_t* __restrict__ vals_out, uint32_t n,
                                                             uint32_t shift, uint32_t stride,
                                                             const uint32_t* __restrict__ offs,
-                                                            uint32_t* totals,
-                                                            const uint32_t* n_dev, uint32_t* exp_table = nullptr,
-                                                            const uint32_t* __restrict__ group_total = nullptr, uint32_t num_tiles = 0)
+                                                            const uint32_t* __restrict__ totals,
+                                                            const uint32_t* n_dev, uint32_t* exp_table = nullptr)
 {
     constexpr uint32_t RADIX = 1u << BITS;
     constexpr uint32_t NW = NT / 64;             // waves
@@ -276,17 +265,8 @@ __global__ __launch_bounds__(NT, (NT == 512 && BITS == 8) ? 6 : 4) void sort_dow
         uint32_t tot[DPT], toff[DPT], tsum = 0;
 #pragma unroll
         for (uint32_t j = 0; j < DPT; j++) {
-            tot[j] = toff[j] = 0u;
-            if (owner) {
-                const uint32_t d = threadIdx.x * DPT + j;
-                if (GROUPED) {
-                    sort_group_lookup(offs, group_total, d, tile, num_tiles, stride, tot[j], toff[j]);
-                    if (blockIdx.x == 0) totals[d] = tot[j];
-                } else {
-                    tot[j] = totals[d];
-                    toff[j] = offs[(size_t)d * stride + tile];
-                }
-            }
+            tot[j] = owner ? totals[threadIdx.x * DPT + j] : 0u;
+            toff[j] = owner ? offs[(size_t)(threadIdx.x * DPT + j) * stride + tile] : 0u;
             tsum += tot[j];
         }
         uint32_t dummy;
@@ -411,15 +391,8 @@ SortScratch sort_scratch_layout(uint32_t n)
     s.digit_total = off; off += (size_t)kSortPasses * kRadixMax * 4;   // totals[pass][digit], written by the scan kernel
     s.hist = off;        off += (tiles * kRadixMax * 4 + 255) / 256 * 256;
     s.offs = off;        off += (tiles * kRadixMax * 4 + 255) / 256 * 256;
-    s.group_total = off; off += (size_t)kRadixMax * kSortMaxGroups * 4;
-    s.arrive = off;      off += 256;
     s.total = off;
     return s;
-}
-
-uint32_t* sort_arrive_words(void* sort_scratch, uint32_t n)
-{
-    return reinterpret_cast<uint32_t*>(static_cast<char*>(sort_scratch) + sort_scratch_layout(n).arrive);
 }
 
 uint32_t* sort_hist_table(void* sort_scratch, uint32_t n)
@@ -448,24 +421,19 @@ bool sort_three_passes(uint32_t tiles)
 template <uint32_t BITS>
 static void radix_pass(const uint32_t* sk, const uint32_t* sv, uint32_t* dk, uint32_t* dv, uint32_t n, uint32_t shift,
                        uint32_t tiles, uint32_t* hist, uint32_t* offs, uint32_t* dt, hipStream_t st, const uint32_t* n_dev,
-                       bool have_hist, bool ident, uint32_t* group_total, uint32_t* arrive)
+                       bool have_hist, bool ident)
 {
     const int vec_ok = (reinterpret_cast<uintptr_t>(sk) & 15u) == 0;
     const uint32_t stride = sort_table_stride(tiles);
-    const bool grouped = sort_grouped(tiles);
     if (!have_hist) {
-        if (sort_upsweep_quads(tiles)) sort_upsweep_kernel<BITS, 512, 4><<<stride / 4, 512, 0, st>>>(sk, n, shift, tiles, stride, hist, n_dev, vec_ok, nullptr, nullptr, nullptr);
-        else sort_upsweep_kernel<BITS, 1024, 1><<<tiles, 1024, 0, st>>>(sk, n, shift, tiles, stride, hist, n_dev, vec_ok, offs, group_total,
-                                                                        grouped ? arrive : nullptr);   // few tiles: 4 keys per thread
+        if (sort_upsweep_quads(tiles)) sort_upsweep_kernel<BITS, 512, 4><<<stride / 4, 512, 0, st>>>(sk, n, shift, tiles, stride, hist, n_dev, vec_ok);
+        else sort_upsweep_kernel<BITS, 1024, 1><<<tiles, 1024, 0, st>>>(sk, n, shift, tiles, stride, hist, n_dev, vec_ok);   // few tiles: 4 keys per thread
     }
-    if (!grouped) {
-        if (tiles <= 1024) sort_scan_kernel<<<(1u << BITS) / 4, 256, 0, st>>>(hist, tiles, stride, offs, dt);
-        else sort_scan_wide_kernel<<<1u << BITS, 256, 0, st>>>(hist, tiles, stride, offs, dt);
-    }
+    if (tiles <= 1024) sort_scan_kernel<<<(1u << BITS) / 4, 256, 0, st>>>(hist, tiles, stride, offs, dt);
+    else sort_scan_wide_kernel<<<1u << BITS, 256, 0, st>>>(hist, tiles, stride, offs, dt);
     // (at most one workgroup per CU: 1024 threads, 4 keys each -- the workgroup's chain is the kernel: 15.8 -> 14.6 us at 1M)
     const bool wide = BITS == 10 && tiles <= 256;
 #define RT_DS(NT_, ID_, EX_) sort_downsweep_kernel<BITS, NT_, ID_, EX_><<<tiles, NT_, 0, st>>>(sk, sv, dk, dv, n, shift, stride, offs, dt, n_dev)
-#define RT_DSG(NT_, ID_) sort_downsweep_kernel<BITS, NT_, ID_, 0, true><<<tiles, NT_, 0, st>>>(sk, sv, dk, dv, n, shift, stride, offs, dt, n_dev, nullptr, group_total, tiles)
 #ifdef RT_SORT_TUNING
     const int exper = tuning_int("RT_SORT_EXP", 0);
     if (exper == 1) { RT_DS(512, false, 1); return; }
@@ -477,21 +445,17 @@ static void radix_pass(const uint32_t* sk, const uint32_t* sv, uint32_t* dk, uin
         return;
     }
 #endif
-    if (grouped) {
-        if (wide) { if (ident) RT_DSG(1024, true); else RT_DSG(1024, false); }
-        else { if (ident) RT_DSG(512, true); else RT_DSG(512, false); }
-    } else if (wide) {
+    if (wide) {
         if (ident) RT_DS(1024, true, 0); else RT_DS(1024, false, 0);
     } else {
         if (ident) RT_DS(512, true, 0); else RT_DS(512, false, 0);
     }
 #undef RT_DS
-#undef RT_DSG
 }
 
 hipError_t launch_radix_sort(uint32_t* keys, uint32_t* vals, uint32_t* tmp_keys, uint32_t* tmp_vals, uint32_t n,
                              void* sort_scratch, hipStream_t st, const uint32_t* n_dev, uint32_t key_bits, bool have_hist0,
-                             bool ident0, bool tickets_zeroed)
+                             bool ident0)
 {
     if (n == 0) return hipSuccess;
     if (n > kSortMaxCount) return hipErrorInvalidValue;   // n * 4 would wrap the descriptors' 32-bit sizes
@@ -500,13 +464,7 @@ hipError_t launch_radix_sort(uint32_t* keys, uint32_t* vals, uint32_t* tmp_keys,
     uint32_t* digit_total = reinterpret_cast<uint32_t*>(base + L.digit_total);
     uint32_t* hist = reinterpret_cast<uint32_t*>(base + L.hist);
     uint32_t* offs = reinterpret_cast<uint32_t*>(base + L.offs);
-    uint32_t* gtot = reinterpret_cast<uint32_t*>(base + L.group_total);
-    uint32_t* arrive = reinterpret_cast<uint32_t*>(base + L.arrive);
     const uint32_t tiles = sort_num_tiles(n);
-    if (sort_grouped(tiles) && !tickets_zeroed) {
-        const hipError_t me = hipMemsetAsync(arrive, 0, kSortMaxGroups * 4, st);
-        if (me != hipSuccess) return me;
-    }
 
     if (key_bits <= 30 && sort_three_passes(tiles)) {
         // Morton keys (30 bits): 3 passes x 10 bits = 60 B/key instead of 80.  An odd number of passes: the input is
@@ -514,7 +472,7 @@ hipError_t launch_radix_sort(uint32_t* keys, uint32_t* vals, uint32_t* tmp_keys,
         uint32_t *sk = tmp_keys, *sv = tmp_vals, *dk = keys, *dv = vals;
         for (uint32_t pass = 0; pass < 3; pass++) {
             radix_pass<10>(sk, sv, dk, dv, n, pass * 10, tiles, hist, offs, digit_total + pass * kRadixMax, st, n_dev,
-                           have_hist0 && pass == 0, ident0 && pass == 0, gtot, arrive);
+                           have_hist0 && pass == 0, ident0 && pass == 0);
             uint32_t* x;
             x = sk; sk = dk; dk = x;
             x = sv; sv = dv; dv = x;
@@ -524,7 +482,7 @@ hipError_t launch_radix_sort(uint32_t* keys, uint32_t* vals, uint32_t* tmp_keys,
     uint32_t *sk = keys, *sv = vals, *dk = tmp_keys, *dv = tmp_vals;
     for (uint32_t pass = 0; pass < kSortPasses; pass++) {
         radix_pass<8>(sk, sv, dk, dv, n, pass * 8, tiles, hist, offs, digit_total + pass * kRadixMax, st, n_dev,
-                      have_hist0 && pass == 0, ident0 && pass == 0, gtot, arrive);
+                      have_hist0 && pass == 0, ident0 && pass == 0);
         uint32_t* x;
         x = sk; sk = dk; dk = x;
         x = sv; sv = dv; dv = x;
@@ -534,7 +492,7 @@ hipError_t launch_radix_sort(uint32_t* keys, uint32_t* vals, uint32_t* tmp_keys,
 
 hipError_t launch_radix_pass(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
                              uint32_t n, uint32_t shift, void* sort_scratch, hipStream_t st, const uint32_t* n_dev,
-                             uint32_t** digit_total, bool tickets_zeroed)
+                             uint32_t** digit_total)
 {
     const SortScratch L = sort_scratch_layout(n);
     char* base = static_cast<char*>(sort_scratch);
@@ -543,13 +501,7 @@ hipError_t launch_radix_pass(const uint32_t* keys_in, const uint32_t* vals_in, u
     if (n == 0) return hipSuccess;
     uint32_t* hist = reinterpret_cast<uint32_t*>(base + L.hist);
     uint32_t* offs = reinterpret_cast<uint32_t*>(base + L.offs);
-    uint32_t* arrive = reinterpret_cast<uint32_t*>(base + L.arrive);
-    if (sort_grouped(sort_num_tiles(n)) && !tickets_zeroed) {
-        const hipError_t me = hipMemsetAsync(arrive, 0, kSortMaxGroups * 4, st);
-        if (me != hipSuccess) return me;
-    }
-    radix_pass<8>(keys_in, vals_in, keys_out, vals_out, n, shift, sort_num_tiles(n), hist, offs, dt, st, n_dev, false, false,
-                  reinterpret_cast<uint32_t*>(base + L.group_total), arrive);
+    radix_pass<8>(keys_in, vals_in, keys_out, vals_out, n, shift, sort_num_tiles(n), hist, offs, dt, st, n_dev, false, false);
     return hipGetLastError();
 }
 

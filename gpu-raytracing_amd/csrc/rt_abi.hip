@@ -155,8 +155,7 @@ int rt_run_bottom_up_build(const rt_build_input* input, const rt_arguments* args
     hipError_t e;
     if (n) {
         // the first launch: scene bounds (partial boxes, folded by the Morton kernels) + the build's initialisations
-        e = launch_scene_aabb_build(input->triangles_in, n, aabb_parts, &nparts, status, arrive, arrive_words,
-                                    sort_arrive_words(s + L.sort, n), st);
+        e = launch_scene_aabb_build(input->triangles_in, n, aabb_parts, &nparts, status, arrive, arrive_words, st);
     } else {
         build_init_kernel<<<1, 256, 0, st>>>(status, p_aabb, aabb_parts, n, arrive, arrive_words);
         e = hipGetLastError();
@@ -179,11 +178,10 @@ int rt_run_bottom_up_build(const rt_build_input* input, const rt_arguments* args
         else
             // (the values of this path are the identity, BottomUpBuilder.cu:113: not written, the sort's first pass regenerates them)
             e = launch_morton_hist(code_dst, nullptr, input->triangles_in, aabb_parts, n, st, nparts, p_aabb,
-                                   s + L.sort, three ? 10 : 8);
+                                   sort_hist_table(s + L.sort, n), three ? 10 : 8);
     }
     if (e == hipSuccess)
-        e = launch_radix_sort(morton, sorted, tmpk, tmpv, n, s + L.sort, st, n_dev, three ? 30 : 32, !pairs, !pairs,
-                              /*tickets_zeroed=*/true);
+        e = launch_radix_sort(morton, sorted, tmpk, tmpv, n, s + L.sort, st, n_dev, three ? 30 : 32, !pairs, !pairs);
     if (e == hipSuccess)
         e = launch_lbvh_levels(input->triangles_in, morton, sorted, n, input->triangles_out, input->nodes_out,
                                s + L.levels, status, st, n_dev);

@@ -49,19 +49,12 @@ inline uint32_t sort_table_stride(uint32_t tiles) { return tiles ? (tiles + 3u) 
 // many tiles: the histogram kernels take four tiles per workgroup and publish 16 bytes per digit
 inline bool sort_upsweep_quads(uint32_t tiles) { return tiles > 512; }
 
-// few tiles: the scan is folded into the histogram kernels (rt_sort_group.hpp): groups of kSortGroup tiles
-constexpr uint32_t kSortGroup = 16, kSortMaxGroups = 32, kSortGroupedMaxTiles = kSortGroup * kSortMaxGroups;
-inline bool sort_grouped(uint32_t tiles) { return tiles <= kSortGroupedMaxTiles && !sort_upsweep_quads(tiles); }
-
 struct SortScratch {
     size_t digit_total;  // uint32[kSortPasses][kRadixMax]
     size_t hist;         // uint32[radix][num_tiles]
     size_t offs;         // uint32[radix][num_tiles]
-    size_t group_total;  // uint32[kRadixMax][kSortMaxGroups] (grouped scan)
-    size_t arrive;       // uint32[kSortMaxGroups] tickets of the grouped scan: zero when a sort starts
     size_t total;
 };
-uint32_t* sort_arrive_words(void* sort_scratch, uint32_t n);   // the kSortMaxGroups ticket words of the sort scratch
 SortScratch sort_scratch_layout(uint32_t n);
 
 // ---- LBVH level geometry (lbvh_levels.hip)
@@ -126,15 +119,14 @@ hipError_t launch_scene_aabb(const rt_triangle* tris, uint32_t n, int* aabb, hip
 // the build's first launch (n > 0): partial boxes by plain stores, *nparts_out of them, + status words and the LBVH level
 // hand-off counters zeroed
 hipError_t launch_scene_aabb_build(const rt_triangle* tris, uint32_t n, int* aabb_parts, uint32_t* nparts_out, uint32_t* status,
-                                   uint32_t* arrive, uint32_t arrive_words, uint32_t* sort_arrive, hipStream_t st);
+                                   uint32_t* arrive, uint32_t arrive_words, hipStream_t st);
 hipError_t launch_morton(uint32_t* codes, uint32_t* values, const rt_triangle* tris, const int* aabb, uint32_t n,
                          hipStream_t st, uint32_t nparts = 1, int* aabb_out = nullptr);
 // the same codes / values plus the first sort pass's tile histograms (digit = low `bits` bits, bits = 8 or 10) in one
 // launch: one workgroup per sort tile
 // values == nullptr: they are not written (the sort's first pass then takes them as the identity)
-// sort_scratch: the sort's scratch (tables, group totals, tickets): with few tiles the kernel also does the grouped scan
 hipError_t launch_morton_hist(uint32_t* codes, uint32_t* values, const rt_triangle* tris, const int* aabb, uint32_t n,
-                              hipStream_t st, uint32_t nparts, int* aabb_out, void* sort_scratch, uint32_t bits);
+                              hipStream_t st, uint32_t nparts, int* aabb_out, uint32_t* hist, uint32_t bits);
 hipError_t launch_morton_pairs(uint32_t* codes, uint32_t* values, const rt_triangle* tris, const int* aabb, uint32_t n,
                                uint8_t* flags, uint32_t* block_sums, uint32_t* num_leaves, hipStream_t st,
                                uint32_t nparts = 1, int* aabb_out = nullptr);
@@ -143,10 +135,9 @@ hipError_t launch_morton_pairs(uint32_t* codes, uint32_t* values, const rt_trian
 // is in (keys, vals) either way.
 // have_hist0: the first pass's tile histograms are already in the sort scratch (launch_morton_hist wrote them).
 // ident0: the input values are the identity (values[i] = i) and are not read.
-// tickets_zeroed: the caller's earlier kernel has zeroed sort_arrive_words() (the build's first kernel); else a memset node
 hipError_t launch_radix_sort(uint32_t* keys, uint32_t* vals, uint32_t* tmp_keys, uint32_t* tmp_vals, uint32_t n,
                              void* sort_scratch, hipStream_t st, const uint32_t* n_dev = nullptr, uint32_t key_bits = 32,
-                             bool have_hist0 = false, bool ident0 = false, bool tickets_zeroed = false);
+                             bool have_hist0 = false, bool ident0 = false);
 bool sort_three_passes(uint32_t tiles);          // keys of <= 30 bits: 3 x 10-bit passes (else 4 x 8)
 // the builder's choice: tiles of the Morton-key sort up to which 3 x 10-bit passes beat 4 x 8-bit (measured: 85 vs 93 us at
 // 245 tiles, 420 vs 300 us at 2444 -- the 1024-digit tables and 16-byte runs cost more than the saved pass)
@@ -160,7 +151,7 @@ hipError_t launch_lbvh_levels(const rt_triangle* tris, const uint32_t* codes, co
 // uint32[256], valid after the pass) = number of keys per digit
 hipError_t launch_radix_pass(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
                              uint32_t n, uint32_t shift, void* sort_scratch, hipStream_t st, const uint32_t* n_dev,
-                             uint32_t** digit_total, bool tickets_zeroed = false);
+                             uint32_t** digit_total);
 // --pairs leaf slots: merge flag per candidate (2k, 2k+1), per-workgroup slot offsets, *num_leaves = L
 hipError_t launch_pair_slots(const rt_triangle* tris, uint32_t n, uint8_t* flags, uint32_t* block_sums,
                              uint32_t* num_leaves, hipStream_t st);

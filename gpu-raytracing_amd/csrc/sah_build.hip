@@ -139,10 +139,9 @@ __device__ __forceinline__ int sah_axis(const float* c)   // SelectAxis (SharedT
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ void sah_init_kernel(SahHeader* H, rt_node* nodes, uint32_t n, uint32_t* sort_arrive)
+__global__ void sah_init_kernel(SahHeader* H, rt_node* nodes, uint32_t n)
 {
     const uint32_t t = threadIdx.x;
-    if (t < kSortMaxGroups) sort_arrive[t] = 0u;   // tickets of the distribution pass's grouped scan (rt_sort_group.hpp)
     if (t < 6) { H->gp[t] = t < 3 ? kEmptyLo : kEmptyHi; H->gc[t] = t < 3 ? kEmptyLo : kEmptyHi; }
     if (t < 8) H->status[t] = (t == 1 || t == 2) ? n : 0u;   // [1] items, [2] leaf records (overwritten by pairs / splits)
     if (t == 0) H->small_count = 0;
@@ -1573,7 +1572,7 @@ hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, boo
     const uint32_t* n_dev = (pairs || splits) ? num_items : nullptr;
     if (levels_run) *levels_run = 0;
 
-    sah_init_kernel<<<1, 256, 0, st>>>(a.H, nodes, n, sort_arrive_words(s + L.sort, a.B));
+    sah_init_kernel<<<1, 256, 0, st>>>(a.H, nodes, n);
     if (n == 0) return hipGetLastError();
     const uint32_t cand = (n + 1) / 2, cblocks = (cand + 255) / 256;
     const uint32_t pblocks = cblocks < 1024 ? cblocks : 1024;
@@ -1612,8 +1611,7 @@ hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, boo
     sah_grid_kernel<<<iblocks < 1024 ? iblocks : 1024, 256, 0, st>>>(aabbs, a.B, n_dev, a.H, a.task_of[1], splits ? 0 : 1);
     // GridBlockDistribute: cell members in ascending leaf index = one stable radix pass on the cell id
     uint32_t* digit_total = nullptr;
-    e = launch_radix_pass(a.task_of[1], a.ids[1], a.task_of[0], a.ids[0], a.B, 0, s + L.sort, st, n_dev, &digit_total,
-                          /*tickets_zeroed=*/true);
+    e = launch_radix_pass(a.task_of[1], a.ids[1], a.task_of[0], a.ids[0], a.B, 0, s + L.sort, st, n_dev, &digit_total);
     if (e != hipSuccess) return e;
     sah_roots_kernel<<<1, 128, 0, st>>>(a, digit_total, aabbs);
     sah_assign_kernel<<<iblocks, 256, 0, st>>>(a, n_dev);
