@@ -565,9 +565,9 @@ def main():
             "hbm_counter_frac": (round(traffic / (serial_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None),
             "north_star_hbm_target": ("not meetable as worded: HBM carries a few % of its peak during traversal because the "
                                       "whole BVH stays in L2 / Infinity Cache; the kernel is limited by L1 address rate "
-                                      "(profiles/r02_trace_l1_pmc.txt, profiles/r02_ta_microbench.txt)" if G <= 1000 else
+                                      "(address_path_utilisation: profiles/trace_l1_pmc.json; profiles/r02_ta_microbench.txt)" if G <= 1000 else
                                       "the one regime where HBM can matter (BVH 1.28 GB > 256 MiB Infinity Cache): see hbm_counter_frac "
-                                      "and profiles/r03_trace_pmc_10m.txt"),
+                                      "and profiles/r04_trace_pmc_10m.txt"),
             "inflight_mean_launch_ms": round(kern_ms, 4),
             "inflight_mean_launch_ms_is": f"mean start-to-end time of the timed region's launches, {S} of which overlap",
         }
@@ -634,8 +634,8 @@ def build_record(n, build_ms, sort_us, tree, G):
                        "achieved": round(80.0 * n / (sort_us * 1e-6) / 1e9, 1), "unit": "GB/s",
                        "frac": round(80.0 * n / (sort_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                        "us_is": "median of 10 runs of rt_radix_sort_u32_pairs_bits(30) on this scene's Morton codes, events around the sort alone",
-                       "yardstick": "rocprim::radix_sort_pairs on the same keys: profiles/r03_sort_yardstick.txt (tools/sort_yardstick.hip)"}
-    stats = os.path.join(ROOT, "profiles", {708: "r03_build_1m_kernel_stats.txt", 2237: "r03_build_10m_kernel_stats.txt"}.get(G, ""))
+                       "yardstick": "rocprim::radix_sort_pairs on the same keys: profiles/r04_sort_yardstick.txt (tools/sort_yardstick.hip)"}
+    stats = os.path.join(ROOT, "profiles", {708: "r04_build1m_kernel_stats.txt", 2237: "r04_build10m_kernel_stats.txt"}.get(G, ""))
     if tree == "bottom-up" and os.path.isfile(stats):
         kern = {}
         for line in open(stats):

@@ -48,6 +48,7 @@ if [ "$MODE" = run ]; then
     python3 bench.py --gpus 2 --steps 20 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_2ranks_one_gpu_rehearsal.json 2>> $O/bench.err
     for cam in a b; do
       for k in 1 4; do
+        echo -n "rt_cli --gpus 1 --inflight $k, grid 708 (1M triangles), 1920x1080, camera $cam: "
         gpu-raytracing_amd/host/rt_cli - --grid 708 --camera $cam --type bottom-up --width 1920 --height 1080 --gpus 1 --inflight $k --frames 40 2>&1 | tail -1
       done
     done > $O/rt_cli_inflight.txt
