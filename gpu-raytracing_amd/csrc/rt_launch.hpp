@@ -103,7 +103,7 @@ BuLayout bu_layout(uint32_t n);
 // ---- SAH build scratch (sah_build.hip)
 struct SahLayout {
     size_t header, aabbs, ids0, ids1, task_of0, task_of1, binof, tasks0, tasks1, splits, bins0, bins1, chunk_hist,
-        chunk_prefix, small, seg_small, sort, pair_flags, pair_sums, item_leaf, split_flags, split_sums_a, split_sums_b;
+        chunk_prefix, small, sort, pair_flags, pair_sums, item_leaf, split_flags, split_sums_a, split_sums_b;
     size_t status;       // uint32[8] inside the header: [0] error flags, [1] number of leaves L
     size_t cell_counts;  // uint32[64] inside the header
     size_t total;

@@ -46,22 +46,21 @@ constexpr uint32_t kSahMaxLevels = 1024;
 constexpr uint32_t kBoundParts = 64, kCellParts = 16;
 constexpr int kEmptyLo = 0x7f7fffff, kEmptyHi = (int)0x80800000;   // ordered-int FLT_MAX / -FLT_MAX (BuildWrapper.cu:170-171)
 constexpr uint32_t kBinWords = 13;        // p box [6], c box [6], count
-constexpr uint32_t kSmallQSegs = 64;      // segments of the level loop's small-task queue (same-address device atomics queue at ~18 ns each)
 constexpr uint32_t kLeafMask = 0x7FFFFFFFu; // item_leaf: TrianglePair index | (two triangles ? 1 << 31 : 0)
 
 enum : uint32_t { kSahErrLocals = 0x100, kSahErrLevels = 0x200 };
 
 struct SahTask { float c[6]; float p[6]; uint32_t start, end, parent_idx, flags; };   // flags bit0: top tree
+struct SahSplit { uint32_t kind, plane, mid, left_id, right_id, pad[3]; };            // kind 1 binned, 2 median
 struct SahSmall { uint32_t start, end, parent_idx, flags; };   // flags bit0 top tree, bit1 id buffer, bit2 top root
 
 struct SahHeader {
     int gp[6], gc[6];                  // scene primitive / centroid bounds, ordered ints
     uint32_t status[8];                // [0] error flags, [1] number of items L, [2] leaf records, [3] split budget asked
-    uint32_t small_count, live_count, pad[2];    // small_count: the common small-task queue; live_count: tasks alive after the last level launch (live list)
+    uint32_t small_count, live_report, pad[2];   // live_report: tasks still alive after the last batch of levels (sah_patch_top_kernel)
     uint32_t cell_count[kSahCells], cell_start[kSahCells], cell_task[kSahCells];
     int cell_p[kSahCells][6], cell_c[kSahCells][6];
-    uint32_t level_count[kSahMaxLevels];   // != 0: some task is alive in this level (a flag since round 4: task ids are positions / 65)
-    uint32_t seg_count[kSmallQSegs];       // the level loop's small-task queue: one segment per chunk index mod kSmallQSegs
+    uint32_t level_count[kSahMaxLevels];
     // same-address device atomics from different workgroups queue at about 50 ns each (they are resolved behind the
     // eight L2s), so the bounds are reduced into several partial copies chosen by workgroup index and folded by the
     // next kernel: chains of 16 instead of 1024
@@ -78,9 +77,7 @@ struct SahArgs {
     uint32_t* task_of[2];
     uint8_t* binof;
     SahTask* tasks[2];
-    SahSmall* seg_small;               // [kSmallQSegs][seg_cap]: small tasks queued by the level loop
-    uint32_t* live_list;               // ids of the tasks still alive after the last level launch (sah_finish_kernel)
-    uint32_t seg_cap;
+    SahSplit* splits;
     int* bins[2];                      // [task][8][13]
     uint32_t* chunk_hist;              // [chunk][2][8]
     uint32_t* chunk_prefix;            // [chunk]
@@ -135,11 +132,6 @@ __device__ __forceinline__ void sah_leaf_desc(const SahArgs& a, rt_node* out, ui
     }
 }
 
-// A task of the level loop holds > kSahSmall items, so tasks of one level start >= kSahSmall + 1 positions apart:
-// id = start / (kSahSmall + 1) is unique per level and needs no allocation (round 4: every chunk of a task derives the
-// children's ids itself, sah_partition_kernel).
-__device__ __forceinline__ uint32_t sah_task_id(uint32_t start) { return start / (kSahSmall + 1u); }
-
 __device__ __forceinline__ int sah_axis(const float* c)   // SelectAxis (SharedTaskBuilder.cu:197-204)
 {
     const float lx = c[3] - c[0], ly = c[4] - c[1], lz = c[5] - c[2];
@@ -152,8 +144,7 @@ __global__ void sah_init_kernel(SahHeader* H, rt_node* nodes, uint32_t n)
     const uint32_t t = threadIdx.x;
     if (t < 6) { H->gp[t] = t < 3 ? kEmptyLo : kEmptyHi; H->gc[t] = t < 3 ? kEmptyLo : kEmptyHi; }
     if (t < 8) H->status[t] = (t == 1 || t == 2) ? n : 0u;   // [1] items, [2] leaf records (overwritten by pairs / splits)
-    if (t == 0) { H->small_count = 0; H->live_count = 0; }
-    if (t < kSmallQSegs) H->seg_count[t] = 0;
+    if (t == 0) H->small_count = 0;
     if (t < kSahCells) {
         H->cell_count[t] = 0; H->cell_start[t] = 0; H->cell_task[t] = kInactive;
         for (int k = 0; k < 6; k++) { H->cell_p[t][k] = k < 3 ? kEmptyLo : kEmptyHi; H->cell_c[t][k] = k < 3 ? kEmptyLo : kEmptyHi; }
@@ -618,8 +609,7 @@ __global__ __launch_bounds__(128) void sah_roots_kernel(SahArgs a, const uint32_
             reinterpret_cast<uint4*>(a.nodes + parent + 1)[0] = make_uint4(0, 0, 0, 0);   // the root's sibling slot: None
             reinterpret_cast<uint4*>(a.nodes + parent + 1)[1] = make_uint4(0, 0, 0, 0);
             if (cnt > kSahSmall) {
-                task = sah_task_id(start);
-                H->level_count[0] = 1u;
+                task = atomicAdd(&H->level_count[0], 1u);
                 SahTask T;
                 for (int j = 0; j < 6; j++) { T.c[j] = cb[j]; T.p[j] = pb[j]; }
                 T.start = start; T.end = start + cnt; T.parent_idx = parent; T.flags = 0;
@@ -636,8 +626,7 @@ __global__ __launch_bounds__(128) void sah_roots_kernel(SahArgs a, const uint32_
     if (t == 64) {   // the top tree: items = the K non-empty cells at positions [n, n + K), root descriptor = slot 0
         uint32_t task = kInactive;
         if (K > kSahSmall) {
-            task = sah_task_id(a.B);
-            H->level_count[0] = 1u;
+            task = atomicAdd(&H->level_count[0], 1u);
             SahTask T;
             for (int j = 0; j < 6; j++) { T.c[j] = ordered_int_to_float(H->gc[j]); T.p[j] = ordered_int_to_float(H->gp[j]); }
             T.start = a.B; T.end = a.B + K; T.parent_idx = 0; T.flags = 1;
@@ -867,215 +856,209 @@ __device__ __forceinline__ uint32_t wave_alloc(uint32_t* counter, bool want, uin
     return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 }
 
-// SelectPlane + PartitionIds in ONE launch (SharedTaskBuilder.cu:297-380, :521-606).  Round 3 had a split kernel between the
-// bin and the partition kernel (one thread per task: plane, parent descriptor, child tasks, per-chunk prefixes) -- a chain
-// of dependent memory round trips of 11 - 14 us per level that nothing overlapped with.  Now every chunk derives what it
-// needs about the (at most kSahMaxLocal) tasks it touches itself:
-//   * plane / kind / mid: sah_select_plane on the task's bins (staged into LDS, one thread per local run) -- redundantly in
-//     every chunk of a task, bit-identically;
-//   * the children's task ids: positions / 65 (sah_task_id), no allocation, no agreement needed;
-//   * the stable partition's "went left before me": a chunk that continues a task sums the bin histograms (chunk_hist) of
-//     the task's earlier chunks for the bins at or below the plane;
-//   * what must happen ONCE per task -- parent descriptor, the children's task records and empty bins, small children
-//     queued, the median split's child boxes -- is done by the chunk that holds the task's first position (its owner).
-// Small children go to a queue segment chosen by chunk index (kSmallQSegs counters instead of one: a level has thousands of
-// owner chunks, and same-address device atomics queue at ~18 ns each), one wave-aggregated atomic per chunk.
-// runs of equal task id a chunk can hold here: tasks in the loop have >= 65 items, so a 256-position chunk meets at most 5
-// of them and at most 6 stretches of finished (inactive) positions around them
-constexpr uint32_t kPartRuns = 16;
-__global__ __launch_bounds__(256) void sah_partition_kernel(SahArgs a, uint32_t lvl, uint32_t final_lvl)
+// one THREAD per task: SelectPlane (SharedTaskBuilder.cu:297-350), parent descriptor, children (RunTask after the
+// bins are known, :521-606).  The two parts that scale with the size of a task -- the child boxes of an object-median
+// split (:465-510) and the per-chunk "goes left" prefix of a task spanning several chunks -- are done by the whole
+// wave, one such task at a time.
+constexpr uint32_t kSplitWaves = 8;
+
+__global__ __launch_bounds__(kSplitWaves * 64) void sah_split_kernel(SahArgs a, uint32_t lvl)
 {
-    if (a.H->level_count[lvl] == 0) return;
+    const uint32_t ntask = a.H->level_count[lvl];
+    // tasks per workgroup: 64 when the level is wide; 8 while it is narrow (the first levels, where every task spans
+    // many chunks and the per-task wave work below would otherwise queue 8 deep in ONE workgroup)
+    const uint32_t tpb = ntask > 2048 ? 64u : 8u;
+    if (blockIdx.x * tpb >= ntask) return;
     const uint32_t cur = lvl & 1, nxt = cur ^ 1;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ uint32_t pf_c0[64], pf_c1[64], pf_plane[64];
+    __shared__ uint32_t pf_n, init_n;
+    __shared__ uint32_t init_ids[128];
+    // the bins of this workgroup's 64 tasks are one contiguous 26 KB block: read it coalesced, keep it in LDS with an
+    // odd row stride (a thread per task reading its row straight from memory touches 64 cache lines per load)
     constexpr uint32_t kRow = 8 * kBinWords + 1;
-    __shared__ int sb[kPartRuns * kRow];            // bins of the local runs' tasks (max words NOT complemented)
-    __shared__ int l_cb[kPartRuns][2][12];          // children's boxes of the runs this chunk owns
-    __shared__ uint32_t ltask[kPartRuns], lfirst[kPartRuns];
-    __shared__ uint32_t l_kind[kPartRuns], l_plane[kPartRuns], l_mid[kPartRuns], l_start[kPartRuns], l_end[kPartRuns];
-    __shared__ uint32_t l_lid[kPartRuns], l_rid[kPartRuns], l_own[kPartRuns];
-    __shared__ uint32_t init_ids[2 * kPartRuns], init_n, s_before;
-    __shared__ SahTask l_T[kPartRuns];
-    __shared__ float c_score[kPartRuns][8];
-    __shared__ uint32_t c_ln[kPartRuns][8];
-    __shared__ uint32_t ws[8];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t chunk = blockIdx.x, pos = chunk * kSahChunk + tid;
-    const uint32_t t = pos < a.M ? a.task_of[cur][pos] : kInactive;
-    const uint32_t t_prev = (tid > 0 && pos - 1 < a.M) ? a.task_of[cur][pos - 1] : kInactive;
-    uint32_t nloc;
-    const uint32_t local = sah_local_runs(t, t_prev, ws, &nloc);
-    if (nloc > kPartRuns) {            // cannot happen (see kPartRuns); sah_bin_kernel reports its own, larger limit
-        if (tid == 0) atomicOr(&a.H->status[0], kSahErrLocals);
-        return;
-    }
-    if (tid == 0 || t != t_prev) ltask[local] = t;
-    if (tid == 0) { init_n = 0; s_before = 0; }
-    __syncthreads();
-    // ---- the bins of this chunk's tasks -> LDS, in the form SelectPlane reads
-    for (uint32_t j = tid; j < nloc * 8 * kBinWords; j += 256) {
-        const uint32_t l = j / (8 * kBinWords), w = j % (8 * kBinWords), wd = w % kBinWords;
-        const uint32_t tl = ltask[l];
-        if (tl != kInactive) {
-            const int v = a.bins[cur][(size_t)tl * 8 * kBinWords + w];
-            sb[l * kRow + w] = (wd < 12 && (wd % 6) >= 3) ? ~v : v;
-        }
-    }
-    __syncthreads();
-    // ---- the split of every local run's task.  EIGHT lanes per run: lane i scores plane i (the boxes left and right of it are
-    // merges of ordered ints -- exact, order-free -- and the score is SelectPlane's own expression, so this is bit-identical
-    // to the serial sah_select_plane of the straggler kernel); the run's first lane then picks the plane exactly as the
-    // serial sweep does (right to left, strict <: the highest plane wins ties) and merges the children's boxes.  (One thread
-    // per run running the whole sweep cost 112 VGPRs -- half the occupancy of a kernel that lives on memory latency.)
-    if (tid < nloc && ltask[tid] != kInactive) l_T[tid] = a.tasks[cur][ltask[tid]];
-    __syncthreads();
+    __shared__ int sbins[64 * kRow];
+    if (threadIdx.x == 0) { pf_n = 0; init_n = 0; }
     {
-        const uint32_t r = tid >> 3, i = tid & 7u;
-        float score = 3.402823466e+38f;
-        uint32_t lni = 0;
-        bool valid = false;
-        if (r < nloc && ltask[r] != kInactive && i < 7 && !(sah_sa(l_T[r].c) <= 0.0f)) {
-            const int* g = &sb[r * kRow];
-            int L[6] = {kEmptyLo, kEmptyLo, kEmptyLo, kEmptyHi, kEmptyHi, kEmptyHi}, R[6] = {kEmptyLo, kEmptyLo, kEmptyLo, kEmptyHi, kEmptyHi, kEmptyHi};
-            uint32_t ln = 0, rn = 0;
-#pragma unroll
-            for (uint32_t bq = 0; bq < 8; bq++) {
-                if (bq <= i) { ibox_merge(L, g + bq * kBinWords); ln += (uint32_t)g[bq * kBinWords + 12]; }
-                else { ibox_merge(R, g + bq * kBinWords); rn += (uint32_t)g[bq * kBinWords + 12]; }
-            }
-            float fl[6], fr[6];
-            ibox_to_float(L, fl);
-            ibox_to_float(R, fr);
-            score = sah_sa(fl) * (float)ln + sah_sa(fr) * (float)rn;
-            valid = ln && rn;
-            lni = ln;
+        const uint32_t first = blockIdx.x * tpb;
+        const uint32_t ntk = min(tpb, ntask - first);
+        const int* src = a.bins[cur] + (size_t)first * 8 * kBinWords;
+        for (uint32_t j = threadIdx.x; j < ntk * 8 * kBinWords; j += kSplitWaves * 64)
+        {
+            const uint32_t wd = (j % (8 * kBinWords)) % kBinWords;
+            const int v = src[j];
+            sbins[(j / (8 * kBinWords)) * kRow + (j % (8 * kBinWords))] = (wd < 12 && (wd % 6) >= 3) ? ~v : v;   // max words are stored complemented
         }
-        if (r < kPartRuns) { c_score[r][i] = score; c_ln[r][i] = valid ? lni : 0u; }   // (ln == 0: not a candidate)
     }
     __syncthreads();
+    if (wave == 0) {
+    const uint32_t w = blockIdx.x * tpb + lane;
+    const bool valid = lane < tpb && w < ntask;
     SahTask T = {};
-    bool own = false, bigL = false, bigR = false;
-    uint32_t kind = 0, plane = 0, mid = 0;
-    if (tid < nloc && ltask[tid] != kInactive) {
-        T = l_T[tid];
-        const uint32_t count = T.end - T.start;
-        kind = 2; mid = T.start + (count >> 1);
-        float best = 3.402823466e+38f;
-        int pl = -1;
+    if (valid) T = a.tasks[cur][w];
+    const uint32_t count = T.end - T.start;
+    const int bias = (T.flags & 1u) ? -2 * (int)a.B : (int)(2 * kSahCells);
+
+    int cb[2][12];   // child boxes, ordered ints: [side][p box 6, c box 6]
 #pragma unroll
-        for (int i = 6; i >= 0; i--)
-            if (c_ln[tid][i] && c_score[tid][i] < best) { best = c_score[tid][i]; pl = i; }
+    for (int s = 0; s < 2; s++)
 #pragma unroll
-        for (int sd = 0; sd < 2; sd++)
+        for (int k = 0; k < 12; k++) cb[s][k] = (k % 6) < 3 ? kEmptyLo : kEmptyHi;
+    uint32_t mid = 0, kind = 2, plane = 0;
+    if (valid && !(sah_sa(T.c) <= 0.0f)) sah_select_plane(&sbins[lane * kRow], T.start, kind, plane, mid, cb);
+    if (valid && kind == 2) mid = T.start + (count >> 1);
+    // object split at the midpoint: child boxes by a wave reduction over the items, one task at a time
+    for (uint64_t todo = __builtin_amdgcn_ballot_w64(valid && kind == 2); todo; todo &= todo - 1) {
+        const int src = __ffsll((unsigned long long)todo) - 1;
+        const uint32_t ts = __shfl(T.start, src, 64), te = __shfl(T.end, src, 64), tm = __shfl(mid, src, 64);
+        int v[2][12];
 #pragma unroll
-            for (int k = 0; k < 12; k++) l_cb[tid][sd][k] = (k % 6) < 3 ? kEmptyLo : kEmptyHi;
-        if (pl >= 0) {
-            kind = 1; plane = (uint32_t)pl; mid = T.start + c_ln[tid][pl];
-            const int* g = &sb[tid * kRow];
-            for (int bq = 0; bq < 8; bq++) {
-                int* dst = &l_cb[tid][bq <= pl ? 0 : 1][0];
-                ibox_merge(dst, g + bq * kBinWords);
-                ibox_merge(dst + 6, g + bq * kBinWords + 6);
-            }
-        }
-        bigL = (mid - T.start) > kSahSmall; bigR = (T.end - mid) > kSahSmall;
-        own = T.start >= chunk * kSahChunk;     // (the run lies in this chunk: its task starts here or in an earlier chunk)
-        l_lid[tid] = bigL ? sah_task_id(T.start) : kInactive;
-        l_rid[tid] = bigR ? sah_task_id(mid) : kInactive;
-    }
-    if (tid < nloc) { l_kind[tid] = kind; l_plane[tid] = plane; l_mid[tid] = mid; l_start[tid] = T.start; l_end[tid] = T.end; l_own[tid] = own ? 1u : 0u; }
-    __syncthreads();
-    // ---- object-median splits this chunk owns: the children's boxes from the items (rare: a centroid box without area)
-    for (uint32_t r = 0; r < nloc; r++) {
-        if (!(l_own[r] && l_kind[r] == 2)) continue;          // (uniform: LDS values)
-        const uint32_t ts = l_start[r], te = l_end[r], tm = l_mid[r];
-        for (uint32_t i = ts + tid; i < te; i += 256) {
+        for (int s = 0; s < 2; s++)
+#pragma unroll
+            for (int k = 0; k < 12; k++) v[s][k] = (k % 6) < 3 ? kEmptyLo : kEmptyHi;
+        for (uint32_t i = ts + lane; i < te; i += 64) {
             float b[6];
             load_box(a.aabbs, a.ids[cur][i], b);
-            int* v = &l_cb[r][i >= tm ? 1 : 0][0];
+            const bool right = i >= tm;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const int ctr = float_to_ordered_int((b[3 + k] + b[k]) * 0.5f);
-                atomicMin(&v[k], float_to_ordered_int(b[k]));
-                atomicMax(&v[3 + k], float_to_ordered_int(b[3 + k]));
-                atomicMin(&v[6 + k], ctr);
-                atomicMax(&v[9 + k], ctr);
+                const int lo = float_to_ordered_int(b[k]), hi = float_to_ordered_int(b[3 + k]);
+                if (right) { v[1][k] = min(v[1][k], lo); v[1][3 + k] = max(v[1][3 + k], hi); v[1][6 + k] = min(v[1][6 + k], ctr); v[1][9 + k] = max(v[1][9 + k], ctr); }
+                else { v[0][k] = min(v[0][k], lo); v[0][3 + k] = max(v[0][3 + k], hi); v[0][6 + k] = min(v[0][6 + k], ctr); v[0][9 + k] = max(v[0][9 + k], ctr); }
             }
         }
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+#pragma unroll
+            for (int k = 0; k < 12; k++) {
+                const int r = (k % 6) < 3 ? wave_min_i32(v[s][k]) : wave_max_i32(v[s][k]);
+                if ((int)lane == src) cb[s][k] = r;
+            }
     }
-    __syncthreads();
-    // ---- once per task (its owner chunk): parent descriptor, child tasks, small children queued.  Wave 0 holds the runs.
-    if (tid < 64) {
-        const int bias = (T.flags & 1u) ? -2 * (int)a.B : (int)(2 * kSahCells);
-        const uint32_t child_index = (uint32_t)(bias + 2 * (int)mid);
-        const bool sL = own && !bigL, sR = own && !bigR;
-        const uint64_t msl = __builtin_amdgcn_ballot_w64(sL), msr = __builtin_amdgcn_ballot_w64(sR);
-        const uint32_t seg = chunk % kSmallQSegs;
-        uint32_t base_small = 0;
-        if (lane == 0 && (msl | msr)) base_small = atomicAdd(&a.H->seg_count[seg], (uint32_t)(__popcll(msl) + __popcll(msr)));
+    const uint32_t child_index = (uint32_t)(bias + 2 * (int)mid);
+    uint32_t cid[2] = {kInactive, kInactive};
+    {
+        // ids of the children: big ones join the next level, small ones the small-task list.  One atomic per counter and
+        // wave (issued back to back), ranks from ballots.
+        const bool bigL = valid && (mid - T.start) > kSahSmall, bigR = valid && (T.end - mid) > kSahSmall;
+        const uint64_t mbl = __builtin_amdgcn_ballot_w64(bigL), mbr = __builtin_amdgcn_ballot_w64(bigR);
+        const uint64_t msl = __builtin_amdgcn_ballot_w64(valid && !bigL), msr = __builtin_amdgcn_ballot_w64(valid && !bigR);
+        uint32_t base_big = 0, base_small = 0;
+        if (lane == 0) {
+            const uint32_t nb = (uint32_t)(__popcll(mbl) + __popcll(mbr)), ns = (uint32_t)(__popcll(msl) + __popcll(msr));
+            if (nb) base_big = atomicAdd(&a.H->level_count[lvl + 1], nb);
+            if (ns) base_small = atomicAdd(&a.H->small_count, ns);
+        }
+        base_big = __shfl(base_big, 0, 64);
         base_small = __shfl(base_small, 0, 64);
         const uint64_t lt = (1ull << lane) - 1ull;
-        const uint32_t qi[2] = {base_small + (uint32_t)__popcll(msl & lt), base_small + (uint32_t)__popcll(msl) + (uint32_t)__popcll(msr & lt)};
-        if (own) {
-            sah_put_node(a.nodes + T.parent_idx, T.p, child_index, 2u, RT_CHILD_BOX);
+        const uint32_t idb[2] = {base_big + (uint32_t)__popcll(mbl & lt), base_big + (uint32_t)__popcll(mbl) + (uint32_t)__popcll(mbr & lt)};
+        const uint32_t ids[2] = {base_small + (uint32_t)__popcll(msl & lt), base_small + (uint32_t)__popcll(msl) + (uint32_t)__popcll(msr & lt)};
 #pragma unroll
-            for (int sd = 0; sd < 2; sd++) {
-                const uint32_t cs = sd ? mid : T.start, ce = sd ? T.end : mid;
-                if (sd ? bigR : bigL) {
-                    SahTask C;
+        for (int s = 0; s < 2; s++) {
+            const uint32_t cs = s ? mid : T.start, ce = s ? T.end : mid;
+            const bool big = s ? bigR : bigL;
+            if (big) {
+                SahTask C;
 #pragma unroll
-                    for (int k = 0; k < 6; k++) { C.p[k] = ordered_int_to_float(l_cb[tid][sd][k]); C.c[k] = ordered_int_to_float(l_cb[tid][sd][6 + k]); }
-                    C.start = cs; C.end = ce; C.parent_idx = child_index + (uint32_t)sd; C.flags = T.flags;
-                    const uint32_t id = sah_task_id(cs);
-                    a.tasks[nxt][id] = C;
-                    init_ids[atomicAdd(&init_n, 1u)] = id;     // its bins are reset by the whole workgroup below
-                    a.H->level_count[lvl + 1] = 1u;            // (a flag: every owner stores the same value)
-                    if (lvl + 1 == final_lvl) a.live_list[atomicAdd(&a.H->live_count, 1u)] = id;   // stragglers: few
-                } else {
-                    const uint32_t q = qi[sd];
-                    if (q < a.seg_cap) a.seg_small[(size_t)seg * a.seg_cap + q] = SahSmall{cs, ce, child_index + (uint32_t)sd, (T.flags & 1u) | (nxt << 1)};
-                    else atomicOr(&a.H->status[0], kSahErrLevels);   // cannot happen: <= 8 small children per chunk and level
-                }
+                for (int k = 0; k < 6; k++) { C.p[k] = ordered_int_to_float(cb[s][k]); C.c[k] = ordered_int_to_float(cb[s][6 + k]); }
+                C.start = cs; C.end = ce; C.parent_idx = child_index + s; C.flags = T.flags;
+                a.tasks[nxt][idb[s]] = C;
+                cid[s] = idb[s];
+                init_ids[atomicAdd(&init_n, 1u)] = idb[s];     // its bins are reset by the whole workgroup below
+            } else if (valid) {
+                a.small[ids[s]] = SahSmall{cs, ce, child_index + (uint32_t)s, (T.flags & 1u) | (nxt << 1)};
             }
         }
     }
-    // ---- the stable partition's prefix for a run that continues an earlier chunk's task (only the first run can)
-    const bool cont = ltask[0] != kInactive && l_kind[0] == 1 && l_start[0] < chunk * kSahChunk;
-    if (cont) {
-        const uint32_t c0 = l_start[0] / kSahChunk, pl = l_plane[0];
-        uint32_t part = 0;
-        for (uint32_t c = c0 + tid; c < chunk; c += 256) {
-            const uint32_t* h = a.chunk_hist + (size_t)c * 16 + (c == c0 ? 8 : 0);
-            for (uint32_t b = 0; b <= pl; b++) part += h[b];
-        }
-        if (part) atomicAdd(&s_before, part);
+    if (valid) {
+        sah_put_node(a.nodes + T.parent_idx, T.p, child_index, 2u, RT_CHILD_BOX);
+        SahSplit S;
+        S.kind = kind; S.plane = plane; S.mid = mid; S.left_id = cid[0]; S.right_id = cid[1];
+        S.pad[0] = S.pad[1] = S.pad[2] = 0;
+        a.splits[w] = S;
     }
+    // tasks that span several chunks need the per-chunk "goes left" prefix: queued for the whole workgroup
+    const uint32_t c0 = T.start / kSahChunk, c1 = valid ? (T.end - 1) / kSahChunk : 0;
+    if (valid && kind == 1 && c1 > c0) {
+        const uint32_t q = atomicAdd(&pf_n, 1u);
+        pf_c0[q] = c0; pf_c1[q] = c1; pf_plane[q] = plane;
+    }
+    }   // wave 0
     __syncthreads();
     // empty bins for the children that join the next level
-    for (uint32_t j = tid; j < init_n * 8 * kBinWords; j += 256) {
+    for (uint32_t j = threadIdx.x; j < init_n * 8 * kBinWords; j += kSplitWaves * 64) {
         const uint32_t wd = j % kBinWords;
         a.bins[nxt][(size_t)init_ids[j / (8 * kBinWords)] * 8 * kBinWords + (j % (8 * kBinWords))] = wd == 12 ? 0 : kEmptyLo;
     }
-    // ---- PartitionIds (SharedTaskBuilder.cu:352-380), stable: ids and the children's task ids go to the other buffer
-    uint32_t k_kind = 0, k_plane = 0, k_mid = 0, k_start = 0;
+    // "goes left" prefix per chunk (stable partition across workgroups).  Long tasks: one wave per task, a wave scan over
+    // its chunks.  Short ones (<= 16 chunks, the bulk at the deeper levels): one thread per (task, chunk) entry, each
+    // summing the few chunks before it -- no serial chain of dependent loads per task.
+    for (uint32_t q = wave; q < pf_n; q += kSplitWaves) {
+        const uint32_t k0 = pf_c0[q], k1 = pf_c1[q], pl = pf_plane[q];
+        if (k1 - k0 <= 16) continue;
+        uint32_t running = 0;
+        for (uint32_t base = k0; base <= k1; base += 64) {
+            const uint32_t c = base + lane;
+            uint32_t v = 0;
+            if (c <= k1) {
+                const uint32_t* h = a.chunk_hist + (size_t)c * 16 + (c == k0 ? 8 : 0);
+                for (uint32_t b = 0; b <= pl; b++) v += h[b];
+            }
+            const uint32_t incl = wave_incl_scan_u32(v, (int)lane);
+            if (c <= k1 && c > k0) a.chunk_prefix[c] = running + incl - v;
+            running += __shfl(incl, 63, 64);
+        }
+    }
+    for (uint32_t j = threadIdx.x; j < pf_n * 16; j += kSplitWaves * 64) {
+        const uint32_t q = j >> 4, e = (j & 15) + 1;          // entry e: chunk k0 + e
+        const uint32_t k0 = pf_c0[q], k1 = pf_c1[q], pl = pf_plane[q];
+        if (k1 - k0 > 16 || k0 + e > k1) continue;
+        uint32_t sum = 0;
+        for (uint32_t c = k0; c < k0 + e; c++) {
+            const uint32_t* h = a.chunk_hist + (size_t)c * 16 + (c == k0 ? 8 : 0);
+            for (uint32_t b = 0; b <= pl; b++) sum += h[b];
+        }
+        a.chunk_prefix[k0 + e] = sum;
+    }
+}
+
+// PartitionIds (SharedTaskBuilder.cu:352-380), stable: ids and the children's task ids go to the other buffer
+__global__ __launch_bounds__(256) void sah_partition_kernel(SahArgs a, uint32_t lvl)
+{
+    if (a.H->level_count[lvl] == 0) return;
+    const uint32_t cur = lvl & 1, nxt = cur ^ 1;
+    __shared__ uint32_t lfirst[kSahMaxLocal];
+    __shared__ uint32_t ws[8];
+    const uint32_t chunk = blockIdx.x, pos = chunk * kSahChunk + threadIdx.x;
+    const uint32_t t = pos < a.M ? a.task_of[cur][pos] : kInactive;
+    const uint32_t t_prev = (threadIdx.x > 0 && pos - 1 < a.M) ? a.task_of[cur][pos - 1] : kInactive;
+    uint32_t nloc;
+    const uint32_t local = sah_local_runs(t, t_prev, ws, &nloc);
+    if (nloc > kSahMaxLocal) return;   // reported by sah_bin_kernel
+    SahSplit S = {};
+    uint32_t start = 0;
     bool left = false;
     if (t != kInactive) {
-        k_kind = l_kind[local]; k_plane = l_plane[local]; k_mid = l_mid[local]; k_start = l_start[local];
-        left = k_kind == 1 ? (a.binof[pos] <= k_plane) : (pos < k_mid);
+        S = a.splits[t];
+        start = a.tasks[cur][t].start;
+        left = S.kind == 1 ? (a.binof[pos] <= S.plane) : (pos < S.mid);
     }
     uint32_t total;
-    const uint32_t ex = block_excl_scan_u32<256>((t != kInactive && k_kind == 1 && left) ? 1u : 0u, ws, &total);
-    if (tid == 0 || t != t_prev) lfirst[local] = ex;
+    const uint32_t ex = block_excl_scan_u32<256>((t != kInactive && S.kind == 1 && left) ? 1u : 0u, ws, &total);
+    if (threadIdx.x == 0 || t != t_prev) lfirst[local] = ex;
     __syncthreads();
     if (pos >= a.M) return;
     if (t == kInactive) { a.task_of[nxt][pos] = kInactive; return; }
     uint32_t dest = pos;
-    if (k_kind == 1) {
-        const uint32_t before = (local == 0 && k_start < chunk * kSahChunk) ? s_before : 0u;
+    if (S.kind == 1) {
+        const uint32_t before = start < chunk * kSahChunk ? a.chunk_prefix[chunk] : 0u;
         const uint32_t lr = before + (ex - lfirst[local]);
-        dest = left ? k_start + lr : k_mid + ((pos - k_start) - lr);
+        dest = left ? start + lr : S.mid + ((pos - start) - lr);
     }
     a.ids[nxt][dest] = a.ids[cur][pos];
-    a.task_of[nxt][dest] = left ? l_lid[local] : l_rid[local];
+    a.task_of[nxt][dest] = left ? S.left_id : S.right_id;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1148,8 +1131,9 @@ constexpr uint32_t kSmallWaves = 2;   // independent waves per workgroup.  A wav
                                       // 2-wave workgroups fit 7 to a CU = 14 waves, 4-wave ones 3 = 12 (202 us), 7-wave ones 2 = 14
                                       // but with the tail of the slowest of seven (208 us); 1 wave: 191 us, 2 waves: 189 us
 
-__device__ __forceinline__ void sah_small_task(const SahArgs& a, SmallSmem& S, const SahSmall R, uint32_t lane)
+__device__ __forceinline__ void sah_small_task(const SahArgs& a, SmallSmem& S, uint32_t task, uint32_t lane)
 {
+    const SahSmall R = a.small[task];
     const uint32_t cnt = R.end - R.start, base = R.start;
     const int bias = (R.flags & 1u) ? -2 * (int)a.B : (int)(2 * kSahCells);
     const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -1355,7 +1339,7 @@ constexpr uint32_t kSahLevelMargin = 2;
 
 __global__ __launch_bounds__(kFinThreads) void sah_finish_kernel(SahArgs a, uint32_t lvl)
 {
-    const uint32_t ntask = a.H->live_count;   // the tasks the last level launch left alive (queued by their parents' owner chunks)
+    const uint32_t ntask = a.H->level_count[lvl];
     if (blockIdx.x >= ntask) return;
     __shared__ SahTask stack[kFinStack];     // flags: bit 0 top tree, bit 1 the id buffer the task's items are in
     __shared__ uint32_t sp, s_kind, s_plane, s_mid;
@@ -1365,7 +1349,7 @@ __global__ __launch_bounds__(kFinThreads) void sah_finish_kernel(SahArgs a, uint
     const uint32_t tid = threadIdx.x;
     for (uint32_t task = blockIdx.x; task < ntask; task += gridDim.x) {
         if (tid == 0) {
-            SahTask T = a.tasks[lvl & 1u][a.live_list[task]];
+            SahTask T = a.tasks[lvl & 1u][task];
             T.flags = (T.flags & 1u) | ((lvl & 1u) << 1);
             stack[0] = T;
             sp = 1;
@@ -1487,34 +1471,15 @@ __global__ __launch_bounds__(kFinThreads) void sah_finish_kernel(SahArgs a, uint
     }
 }
 
-// The small tasks: the common queue [0, H->small_count) (cell roots, the straggler kernel's) and the kSmallQSegs segments the
-// level loop filled.  A fixed grid, every wave takes tasks with a grid stride over the concatenation; the counts are read on
-// the device: no host round trip.
-__global__ __launch_bounds__(kSmallWaves * 64) void sah_small_kernel(SahArgs a)
+// The small tasks [first, H->small_count): a fixed grid, every wave takes tasks with a grid stride.  The count is read
+// on the device: no host round trip.
+__global__ __launch_bounds__(kSmallWaves * 64) void sah_small_kernel(SahArgs a, uint32_t first)
 {
     __shared__ SmallSmem SS[kSmallWaves];
-    __shared__ uint32_t pref[kSmallQSegs + 2];     // pref[0] = 0, pref[1] = small_count, pref[2 + s] = ... + seg_count[0 .. s]
+    const uint32_t nsmall = a.H->small_count;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (wave == 0) {
-        const uint32_t c = min(a.H->seg_count[lane], a.seg_cap);     // (64 lanes = kSmallQSegs)
-        const uint32_t incl = wave_incl_scan_u32(c) + a.H->small_count;
-        pref[2 + lane] = incl;
-        if (lane == 0) { pref[0] = 0; pref[1] = a.H->small_count; }
-    }
-    static_assert(kSmallQSegs == 64, "one lane per segment");
-    __syncthreads();
-    const uint32_t nsmall = pref[kSmallQSegs + 1];
-    for (uint32_t task = blockIdx.x * kSmallWaves + wave; task < nsmall; task += gridDim.x * kSmallWaves) {
-        SahSmall R;
-        if (task < pref[1]) {
-            R = a.small[task];
-        } else {
-            uint32_t sg = 0;                        // the segment holding `task`: largest sg with pref[1 + sg] <= task
-#pragma unroll
-            for (uint32_t step = kSmallQSegs / 2; step; step >>= 1) sg += (pref[1 + sg + step] <= task) ? step : 0u;
-            R = a.seg_small[(size_t)sg * a.seg_cap + (task - pref[1 + sg])];
-        }
-        sah_small_task(a, SS[wave], R, lane);
+    for (uint32_t task = first + blockIdx.x * kSmallWaves + wave; task < nsmall; task += gridDim.x * kSmallWaves) {
+        sah_small_task(a, SS[wave], task, lane);
         wave_lds_sync();
     }
 }
@@ -1525,6 +1490,7 @@ __global__ void sah_patch_top_kernel(SahArgs a, int records_in_status2, uint32_t
 {
     const uint32_t s = threadIdx.x;
     if (s == 0 && !records_in_status2) a.H->status[2] = a.H->status[1];   // without splits: one item per leaf record
+    if (s == 0) a.H->live_report = a.H->level_count[lvl];                 // next to the status words: the host reads both with ONE copy
     if (s >= 2 * kSahCells) return;
     rt_node* nd = a.nodes + s;
     if ((nd->w28 >> 29) != RT_CHILD_BOX || (nd->w12 >> 29) != 0) return;
@@ -1554,13 +1520,12 @@ SahLayout sah_layout(uint32_t n)
     L.item_leaf = off;    off = al(off + B * 4 + 4);
     L.tasks0 = off;       off = al(off + TA * sizeof(SahTask));
     L.tasks1 = off;       off = al(off + TA * sizeof(SahTask));
-    L.splits = off;       off = al(off + TA * 4);                                   // (the live list of sah_finish_kernel)
+    L.splits = off;       off = al(off + TA * sizeof(SahSplit));
     L.bins0 = off;        off = al(off + TA * 8 * kBinWords * 4);
     L.bins1 = off;        off = al(off + TA * 8 * kBinWords * 4);
     L.chunk_hist = off;   off = al(off + chunks * 16 * 4);
     L.chunk_prefix = off; off = al(off + chunks * 4);
     L.small = off;        off = al(off + M * sizeof(SahSmall));
-    L.seg_small = off;    off = al(off + (size_t)kSmallQSegs * ((chunks + kSmallQSegs - 1) / kSmallQSegs) * kSahChunk * sizeof(SahSmall));
     L.sort = off;         off = al(off + sort_scratch_layout((uint32_t)B).total);
     L.pair_flags = off;   off = al(off + ((size_t)n + 1) / 2 + 1);
     L.pair_sums = off;    off = al(off + (((size_t)n + 1) / 2 / 256 + 2) * 4);
@@ -1593,8 +1558,7 @@ hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, boo
     a.binof = reinterpret_cast<uint8_t*>(s + L.binof);
     a.tasks[0] = reinterpret_cast<SahTask*>(s + L.tasks0);
     a.tasks[1] = reinterpret_cast<SahTask*>(s + L.tasks1);
-    a.live_list = reinterpret_cast<uint32_t*>(s + L.splits);
-    a.seg_small = reinterpret_cast<SahSmall*>(s + L.seg_small);
+    a.splits = reinterpret_cast<SahSplit*>(s + L.splits);
     a.bins[0] = reinterpret_cast<int*>(s + L.bins0);
     a.bins[1] = reinterpret_cast<int*>(s + L.bins1);
     a.chunk_hist = reinterpret_cast<uint32_t*>(s + L.chunk_hist);
@@ -1653,7 +1617,8 @@ hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, boo
     sah_assign_kernel<<<iblocks, 256, 0, st>>>(a, n_dev);
 
     const uint32_t chunks = (a.M + kSahChunk - 1) / kSahChunk;
-    a.seg_cap = ((chunks + kSmallQSegs - 1) / kSmallQSegs) * kSahChunk;
+    const uint32_t TA = a.M / (kSahSmall + 1) + 2;
+    const uint32_t split_blocks = (TA + 63) / 64 > 2048 / 8 ? (TA + 63) / 64 : (TA < 2048 ? (TA + 7) / 8 : 2048 / 8);
     uint32_t lvl = 0;
     // levels until every task has <= kSahSmall items: about log2(items per cell / kSahSmall) when the splits are
     // balanced, plus a margin.  The number of launches is FIXED by n: kernels of a level nobody reaches return at once
@@ -1665,13 +1630,13 @@ hipError_t launch_sah_build(const rt_triangle* tris, uint32_t n, bool pairs, boo
     if (const char* e = getenv("RT_SAH_BATCH_DELTA")) { const int b = (int)batch + atoi(e); batch = b < 0 ? 0u : (uint32_t)b; }   // tools/sah_loop.py sweeps
 #endif
     constexpr uint32_t kSmallGrid = 32768 / kSmallWaves;
-    const uint32_t final_lvl = batch < kSahMaxLevels - 1 ? batch : kSahMaxLevels - 1;   // the level whose tasks go to sah_finish_kernel
     for (uint32_t i = 0; i < batch && lvl + 1 < kSahMaxLevels; i++, lvl++) {
         sah_bin_kernel<<<chunks, 256, 0, st>>>(a, lvl);
-        sah_partition_kernel<<<chunks, 256, 0, st>>>(a, lvl, final_lvl);
+        sah_split_kernel<<<split_blocks, kSplitWaves * 64, 0, st>>>(a, lvl);
+        sah_partition_kernel<<<chunks, 256, 0, st>>>(a, lvl);
     }
     sah_finish_kernel<<<kFinGrid, kFinThreads, 0, st>>>(a, lvl);
-    sah_small_kernel<<<kSmallGrid, kSmallWaves * 64, 0, st>>>(a);
+    sah_small_kernel<<<kSmallGrid, kSmallWaves * 64, 0, st>>>(a, 0u);
     // The patch copies every cell's sub-root descriptor (w12 / w28 of the cell tree's root slot) into its top-tree leaf.
     // Invariant: a cell's root is a level-0 task, a straggler's ancestor or a small task queued by sah_roots_kernel -- all
     // of them have written their descriptor when the three kernels above are done.
