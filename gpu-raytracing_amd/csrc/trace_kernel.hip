@@ -61,6 +61,23 @@ constexpr int kParkNum = 8, kParkDen = 1;   // (round-2 sweep under the chunked 
 
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
+// ---- publication of the test counters (see the end of trace_kernel).  The caller's four counters are ONE 32-byte target
+// for every workgroup of a frame, and same-address device atomics queue at the memory side at ~18 ns each: 8,100
+// workgroups = 0.15 ms behind which a sparse frame waits (camera B of the bench: 2,690 instead of 3,330 Mrays/s serial).
+// So a launch borrows one of kCtrSlots slots of module-static device memory: workgroup b adds its sums into row b mod
+// kCtrSub of the slot (16 queues instead of one) and takes a ticket on that row; the last ticket of a row takes a ticket on the
+// slot; the last of those folds the 16 rows into the caller's counters and leaves the slot zeroed (nobody waits; the
+// "last arriver continues" hand-off of lbvh_levels.hip).  Slots are handed out round-robin by launch_trace: two launches
+// share one only if more than kCtrSlots launches with counters are in flight at once.
+constexpr uint32_t kCtrSlots = 256, kCtrSub = 16;
+struct alignas(64) CtrSlot {
+    // one 64-byte line per row: [box, tri, box-phase steps, leaf-phase steps, the row's tickets, pad x 3] -- the ticket lives
+    // in its row's line: sixteen tickets in ONE line would queue exactly like the single target this replaces
+    unsigned long long part[kCtrSub][8];
+    unsigned long long top, pad[7];
+};
+__device__ CtrSlot g_ctr[kCtrSlots];
+
 struct TraceParams {
     const rt_node* nodes;
     const rt_triangle_pair* leaves;
@@ -78,6 +95,7 @@ struct TraceParams {
     // (t % strip_tiles) of strip  strip_first + (t / strip_tiles) * strip_stride  and is stored at tile row t (compactly)
     uint32_t strip_tiles, strip_first, strip_stride;
     int park_num, park_den;
+    uint32_t ctr_slot;   // counters != null: this launch's slot of g_ctr
 };
 
 struct Ray {
@@ -715,12 +733,9 @@ void trace_kernel(TraceParams p)
         reinterpret_cast<uint32_t*>(p.rgba8)[(size_t)out_y * p.w + x] = px;
     }
     if (p.counters) {
-        // The four counters are ONE 32-byte target for every wave of the frame, and same-address device atomics queue at the
-        // memory side at ~11 ns each: four atomics per wave (round 2) were 130 k queued atomics = 1.4 ms per 1080p frame --
-        // more than the whole frame through a SAH tree (rt_cli, which passes counters like the reference's Trace() does,
-        // showed it; bench.py times its frames without counters).  Now the workgroup's waves add into LDS, and the LAST
-        // wave to finish (an LDS arrival count: no barrier, nobody waits) issues one atomic instruction whose four lanes
-        // carry the four sums: one memory-side request per workgroup.
+        // The workgroup's waves add into LDS, and the LAST wave to finish (an LDS arrival count: no barrier, nobody waits)
+        // publishes the four sums (round 2 issued four device atomics per wave on the caller's counters: 130 k queued
+        // same-address atomics = 1.4 ms per 1080p frame).
         const uint32_t bsum = wave_sum_u32(box_acc), tsum = wave_sum_u32(tri_acc);  // <= 64 * 2^26: no overflow per wave
         uint32_t last = 0;
         if (lane == 0) {
@@ -732,9 +747,37 @@ void trace_kernel(TraceParams p)
             last = atomicAdd(&carrive, 1u) == (uint32_t)kTraceWaves - 1u ? 1u : 0u;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
-        if (__builtin_amdgcn_readfirstlane((int)last) && lane < 4) {
-            const unsigned long long v = *(volatile unsigned long long*)&csum[lane];
-            if (v) atomicAdd(&p.counters[lane], v);
+        if (__builtin_amdgcn_readfirstlane((int)last)) {   // the workgroup's last wave: publish (see g_ctr above)
+            CtrSlot& S = g_ctr[p.ctr_slot];
+            const uint32_t sub = blockIdx.x % kCtrSub;
+            if (lane < 4) {
+                const unsigned long long v = *(volatile unsigned long long*)&csum[lane];
+                // a RETURNING atomic: its value coming back means the add has been performed at the memory side, so the
+                // ticket below cannot overtake it
+                const unsigned long long old = v ? __hip_atomic_fetch_add(&S.part[sub][lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                asm volatile("" ::"v"((uint32_t)old), "v"((uint32_t)(old >> 32)) : "memory");
+            }
+            uint32_t fin = 0;
+            if (lane == 0) {
+                const uint32_t members = (gridDim.x - sub + kCtrSub - 1) / kCtrSub;
+                if (__hip_atomic_fetch_add(&S.part[sub][4], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull == members) {
+                    const uint32_t rows = min(gridDim.x, kCtrSub);
+                    fin = __hip_atomic_fetch_add(&S.top, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull == rows ? 1u : 0u;
+                }
+            }
+            if (__builtin_amdgcn_readfirstlane((int)fin)) {
+                // every workgroup of the launch has added its sums: fold the rows (lane = row * 4 + counter), hand them to the
+                // caller, leave the slot zeroed for its next user
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                unsigned long long* cell = &S.part[lane >> 2][lane & 3];
+                unsigned long long v = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(cell, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane < (int)kCtrSub) __hip_atomic_store(&S.part[lane][4], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) __hip_atomic_store(&S.top, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int off = 4; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+                if (lane < 4 && v) atomicAdd(&p.counters[lane], v);
+            }
         }
     }
 }
@@ -757,6 +800,8 @@ hipError_t launch_trace(const TraceLaunch& t, hipStream_t st)
     p.rgba8 = t.rgba8;
     p.w = t.w; p.h = t.h; p.y0 = t.y0; p.y1 = t.y1; p.spp = t.spp;
     p.counters = reinterpret_cast<unsigned long long*>(t.counters);
+    static std::atomic<uint32_t> ctr_seq{0};
+    p.ctr_slot = t.counters ? ctr_seq.fetch_add(1u, std::memory_order_relaxed) % kCtrSlots : 0u;
     p.tiles_x = (t.w + 7) / 8;
     uint32_t tiles_y = (t.y1 - t.y0 + 7) / 8;
     p.strip_tiles = t.strip_rows / 8;

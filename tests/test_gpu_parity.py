@@ -531,3 +531,45 @@ def test_build_is_independent_of_stale_scratch(rt, scenes, ora, poison, variant)
         what = f"{variant} n={n} poison={poison:#x}"
         assert_nodes_equal(rt.to_host(inp.nodes_out, rt.NODE, o["nodes"].shape[0]), o["nodes"], what)
         assert rt.to_host(inp.triangles_out, rt.TRIANGLE_PAIR, L).tobytes() == o["leaves"].tobytes(), what
+
+
+def test_counters_of_concurrent_launches_do_not_mix(rt, scenes, ora):
+    """The test counters are published through slots of module-static device memory (trace_kernel.hip g_ctr: a launch's
+    workgroups add into 16 rows of its slot, the last arriver folds them into the caller's buffer and zeroes the slot).
+    400 launches on 8 streams, each with its own counter buffer, several frame sizes and row bands (1 .. 8100 workgroups, i.e.
+    fewer rows than 16 too), slots reused after 256 launches: every buffer must hold exactly its own frame's sums."""
+    import torch
+    from helpers import gpu_build
+    tris = scenes.grid_mesh(60, 3)
+    g, o = gpu_build(tris), ora.build_bvh(tris)
+    inp = g["inp"]
+    cams = [scenes.camera_a(60), scenes.camera_b(60)]
+    cam_d = [rt.to_device(c) for c in cams]
+    shapes = [(64, 8, None), (8, 8, None), (200, 120, None), (320, 200, (16, 120)), (1920, 1080, None), (96, 40, (8, 9))]
+    expect = {}
+    for ci, cam in enumerate(cams):
+        for si, (w, h, rows) in enumerate(shapes):
+            if w * h > 100000:
+                continue                                   # (the big frame's sums come from a single GPU launch below)
+            _, oc = ora.trace(o["leaves"], o["nodes"], 0, 2, cam, w, h, rows=rows)
+            expect[(ci, si)] = (int(oc[0]), int(oc[1]))
+    frames = {s: torch.zeros(s[0] * s[1] * 4, dtype=torch.uint8, device="cuda") for s in {(w, h) for w, h, _ in shapes}}
+    for ci in range(2):                                    # reference sums of the 1080p frame: one launch alone
+        c = torch.zeros(4, dtype=torch.int64, device="cuda")
+        rt.Trace(inp.triangles_out, inp.nodes_out, frames[(1920, 1080)], (1920, 1080), cam_d[ci], 0, 2, counters=c)
+        torch.cuda.synchronize()
+        expect[(ci, 4)] = (int(c[0]), int(c[1]))
+    streams = [torch.cuda.Stream() for _ in range(8)]
+    bufs, keys = [torch.zeros(4, dtype=torch.int64, device="cuda") for _ in range(400)], []
+    torch.cuda.synchronize()                               # (the buffers are zero before any side stream touches them)
+    for k in range(400):
+        ci, si = k % 2, (k * 7 + k // 5) % len(shapes)
+        w, h, rows = shapes[si]
+        c = bufs[k]
+        with torch.cuda.stream(streams[k % 8]):
+            rt.Trace(inp.triangles_out, inp.nodes_out, frames[(w, h)], (w, h), cam_d[ci], 0, 2, counters=c, rows=rows)
+        keys.append((ci, si))
+    torch.cuda.synchronize()
+    got = torch.stack(bufs).cpu().numpy()
+    bad = [(k, keys[k], tuple(got[k][:2]), expect[keys[k]]) for k in range(400) if (int(got[k][0]), int(got[k][1])) != expect[keys[k]]]
+    assert not bad, bad[:5]
