@@ -418,6 +418,12 @@ bool sort_three_passes(uint32_t tiles)
     return tiles <= kSort3PassMaxTiles;
 }
 
+// threads of the few-tiles kernels: 4 keys per thread in the histogram kernel; the down-sweep's count is an experiment knob
+constexpr uint32_t kUpNT = kSortTile / 4;
+#ifndef RT_SORT_DS_NT
+#define RT_SORT_DS_NT 1024
+#endif
+constexpr uint32_t kWideNT = RT_SORT_DS_NT;
 template <uint32_t BITS>
 static void radix_pass(const uint32_t* sk, const uint32_t* sv, uint32_t* dk, uint32_t* dv, uint32_t n, uint32_t shift,
                        uint32_t tiles, uint32_t* hist, uint32_t* offs, uint32_t* dt, hipStream_t st, const uint32_t* n_dev,
@@ -427,12 +433,12 @@ static void radix_pass(const uint32_t* sk, const uint32_t* sv, uint32_t* dk, uin
     const uint32_t stride = sort_table_stride(tiles);
     if (!have_hist) {
         if (sort_upsweep_quads(tiles)) sort_upsweep_kernel<BITS, 512, 4><<<stride / 4, 512, 0, st>>>(sk, n, shift, tiles, stride, hist, n_dev, vec_ok);
-        else sort_upsweep_kernel<BITS, 1024, 1><<<tiles, 1024, 0, st>>>(sk, n, shift, tiles, stride, hist, n_dev, vec_ok);   // few tiles: 4 keys per thread
+        else sort_upsweep_kernel<BITS, kUpNT, 1><<<tiles, kUpNT, 0, st>>>(sk, n, shift, tiles, stride, hist, n_dev, vec_ok);   // few tiles: 4 keys per thread
     }
     if (tiles <= 1024) sort_scan_kernel<<<(1u << BITS) / 4, 256, 0, st>>>(hist, tiles, stride, offs, dt);
     else sort_scan_wide_kernel<<<1u << BITS, 256, 0, st>>>(hist, tiles, stride, offs, dt);
     // (at most one workgroup per CU: 1024 threads, 4 keys each -- the workgroup's chain is the kernel: 15.8 -> 14.6 us at 1M)
-    const bool wide = BITS == 10 && tiles <= 256;
+    const bool wide = BITS == 10 && tiles <= 256 * kSortTileScale;
 #define RT_DS(NT_, ID_, EX_) sort_downsweep_kernel<BITS, NT_, ID_, EX_><<<tiles, NT_, 0, st>>>(sk, sv, dk, dv, n, shift, stride, offs, dt, n_dev)
 #ifdef RT_SORT_TUNING
     const int exper = tuning_int("RT_SORT_EXP", 0);
@@ -446,7 +452,7 @@ static void radix_pass(const uint32_t* sk, const uint32_t* sv, uint32_t* dk, uin
     }
 #endif
     if (wide) {
-        if (ident) RT_DS(1024, true, 0); else RT_DS(1024, false, 0);
+        if (ident) RT_DS(kWideNT, true, 0); else RT_DS(kWideNT, false, 0);
     } else {
         if (ident) RT_DS(512, true, 0); else RT_DS(512, false, 0);
     }

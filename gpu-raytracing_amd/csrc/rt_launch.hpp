@@ -31,9 +31,14 @@ struct PerDeviceOnce {
 };
 
 // ---- radix sort geometry (radix_sort.hip)
-constexpr uint32_t kSortThreads = 256;
-constexpr uint32_t kSortItems = 16;
-constexpr uint32_t kSortTile = kSortThreads * kSortItems;  // keys per workgroup
+// keys per workgroup (tile).  4096 shipped; -DRT_SORT_TILE=2048 / 1024 and -DRT_SORT_DS_NT=<threads of the few-tiles down-sweep>
+// are experiment arms (profiles/r04_sort_experiments.txt (b)): every table and threshold below scales with the tile
+#ifndef RT_SORT_TILE
+#define RT_SORT_TILE 4096
+#endif
+constexpr uint32_t kSortTile = RT_SORT_TILE;
+constexpr uint32_t kSortTileScale = 4096 / kSortTile;      // tiles per 4096 keys
+static_assert(kSortTile == 4096 || kSortTile == 2048 || kSortTile == 1024, "tile sizes the kernels are written for");
 constexpr uint32_t kRadixBits = 8;
 constexpr uint32_t kRadix = 1u << kRadixBits;
 constexpr uint32_t kSortPasses = 4;
@@ -47,7 +52,7 @@ inline uint32_t sort_num_tiles(uint32_t n) { return (n + kSortTile - 1) / kSortT
 // covers four tiles)
 inline uint32_t sort_table_stride(uint32_t tiles) { return tiles ? (tiles + 3u) & ~3u : 4u; }
 // many tiles: the histogram kernels take four tiles per workgroup and publish 16 bytes per digit
-inline bool sort_upsweep_quads(uint32_t tiles) { return tiles > 512; }
+inline bool sort_upsweep_quads(uint32_t tiles) { return tiles > 512 * kSortTileScale; }
 
 struct SortScratch {
     size_t digit_total;  // uint32[kSortPasses][kRadixMax]
@@ -141,7 +146,7 @@ hipError_t launch_radix_sort(uint32_t* keys, uint32_t* vals, uint32_t* tmp_keys,
 bool sort_three_passes(uint32_t tiles);          // keys of <= 30 bits: 3 x 10-bit passes (else 4 x 8)
 // the builder's choice: tiles of the Morton-key sort up to which 3 x 10-bit passes beat 4 x 8-bit (measured: 85 vs 93 us at
 // 245 tiles, 420 vs 300 us at 2444 -- the 1024-digit tables and 16-byte runs cost more than the saved pass)
-constexpr uint32_t kSort3PassMaxTiles = 512;
+constexpr uint32_t kSort3PassMaxTiles = 512 * kSortTileScale;
 uint32_t* sort_hist_table(void* sort_scratch, uint32_t n);   // hist[radix][tiles] of the sort scratch
 hipError_t launch_lbvh_levels(const rt_triangle* tris, const uint32_t* codes, const uint32_t* sorted_indices,
                               uint32_t n, rt_triangle_pair* leaves, rt_node* nodes, void* level_scratch,

@@ -36,4 +36,7 @@ ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * N)]
 for i in range(N):
     ev[2 * i].record(); build(); ev[2 * i + 1].record()
 torch.cuda.synchronize()
-print("build ms:", [round(ev[2 * i].elapsed_time(ev[2 * i + 1]), 4) for i in range(N)], "n =", inp.num_triangles)
+ms = sorted(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(1, N)) if N > 1 else [ev[0].elapsed_time(ev[1])]
+nn = inp.num_triangles
+chk = int(inp.nodes_out[: 64 * max(nn - 1, 1)].view(torch.int32).to(torch.int64).sum().item()) ^ int(inp.triangles_out[: 64 * nn].view(torch.int32).to(torch.int64).sum().item())
+print("build ms:", [round(ev[2 * i].elapsed_time(ev[2 * i + 1]), 4) for i in range(N)], "n =", nn, f"median {ms[len(ms) // 2]:.4f}", f"checksum {chk & 0xFFFFFFFFFFFF:#x}")
