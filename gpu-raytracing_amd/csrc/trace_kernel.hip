@@ -281,6 +281,9 @@ __device__ __forceinline__ bool trace_ray(const TraceParams& p, Ray& r, Hit& h, 
     prefetch_pair<PF>(p, t);
     bool tri_hit = false;
     uint32_t nbox = 0, nleaf = 0;
+#ifdef RT_EXP_UNIFORM_STATS
+    uint32_t ustat[4] = {0, 0, 0, 0};
+#endif
 
     while (true) {
         // ---------------------------------------------------- box phase: step while enough lanes want to
@@ -290,6 +293,19 @@ __device__ __forceinline__ bool trace_ray(const TraceParams& p, Ray& r, Hit& h, 
             parked = __builtin_amdgcn_ballot_w64((t.phase - 1u) < 2u);
             if (stepping == 0 || __popcll(stepping) * p.park_den < __popcll(parked) * p.park_num) break;
             nbox += 2;   // two box steps per vote (below)
+#ifdef RT_EXP_UNIFORM_STATS   // experiment: how often do the stepping lanes of a wave sit on <= 1 / 2 / 4 distinct pairs?  (steps[1] = histogram packed 16 bits each)
+            {
+                uint64_t rest = stepping;
+                int distinct = 0;
+                while (rest && distinct < 5) {
+                    const int l0 = __ffsll((unsigned long long)rest) - 1;
+                    const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)t.cur, l0);
+                    rest &= ~__builtin_amdgcn_ballot_w64(t.phase == PH_STEP && t.cur == c0);
+                    distinct++;
+                }
+                ustat[distinct <= 1 ? 0 : (distinct == 2 ? 1 : (distinct <= 4 ? 2 : 3))]++;
+            }
+#endif
             if (t.phase == PH_STEP) box_step<PF>(p, r, t);
             // second step under the same vote: halves the per-step loop overhead (ballots, branch, copies)
             if (t.phase == PH_STEP) box_step<PF>(p, r, t);
@@ -320,7 +336,11 @@ __device__ __forceinline__ bool trace_ray(const TraceParams& p, Ray& r, Hit& h, 
             if (t.phase == PH_STEP) { t.advance(); prefetch_pair<PF>(p, t); }
         }
     }
-#ifndef RT_TRACE_NO_STEPS
+#ifdef RT_EXP_UNIFORM_STATS
+    steps[0] += ustat[RT_EXP_UNIFORM_STATS == 1 ? 0 : 2];   // votes whose stepping lanes sit on 1 (arm 1) / 3-4 (arm 2) distinct pairs
+    steps[1] += ustat[RT_EXP_UNIFORM_STATS == 1 ? 1 : 3];   // ... 2 (arm 1) / more than 4 (arm 2)
+    (void)nbox; (void)nleaf;
+#elif !defined(RT_TRACE_NO_STEPS)
     steps[0] += nbox;
     steps[1] += nleaf;
 #endif
