@@ -19,3 +19,14 @@ for V in base "$@"; do
   python3 tools/pmc_summary.py $O/pmc_${V}_TCC_HIT_sum 2>/dev/null | grep -E "trace_kernel<1>|TCC_" | sed "s/^/$V  /" | tee -a $R
   python3 tools/pmc_summary.py $O/pmc_${V}_FETCH_SIZE 2>/dev/null | grep -A1 "trace_kernel<1>" | grep FETCH | sed "s/^/$V  /" | tee -a $R
 done
+# ---- scene-size sweep of the same variants (where does the pair prefetch start to pay?): G=1000 -> 2.0M, 1500 -> 4.5M, 2237 -> 10M
+if [ -n "$RT_SIZE_SWEEP" ]; then
+  : > $O/size_sweep.txt
+  for V in base "$@"; do
+    if [ $V = base ]; then unset RT_LIB; else export RT_LIB=gpu-raytracing_amd/csrc/librt_amd_exp_$V.so; fi
+    for G in 1000 1500 2237; do for cam in a b; do
+      python3 tools/trace_exp.py --grid $G --camera $cam --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $O/b.json 2> $O/b.err || { tail -3 $O/b.err; exit 1; }
+      python3 -c "import json; d=json.loads(open('$O/b.json').read()); print('$V', 'G=$G cam $cam', 'inflight', d['value'], 'serial', d['serial_mrays'])" | tee -a $O/size_sweep.txt
+    done; done
+  done
+fi
