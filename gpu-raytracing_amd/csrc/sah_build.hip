@@ -651,11 +651,13 @@ __global__ __launch_bounds__(256) void sah_assign_kernel(SahArgs a, const uint32
 
 // ---------------------------------------------------------------------------------------------
 // runs of equal task id inside a chunk: local index of this position's run, number of runs
+// (its barriers order LDS only: the level kernels issue their global loads BEFORE it and let them fly across the scan -- a
+// __syncthreads() would wait for them)
 __device__ __forceinline__ uint32_t sah_local_runs(uint32_t t, uint32_t t_prev, uint32_t* ws, uint32_t* nloc)
 {
     const uint32_t flag = (threadIdx.x > 0 && t != t_prev) ? 1u : 0u;
     uint32_t total;
-    const uint32_t ex = block_excl_scan_u32<256>(flag, ws, &total);
+    const uint32_t ex = block_excl_scan_lds<256>(flag, ws, &total);
     *nloc = total + 1;
     return ex + flag;
 }
@@ -879,6 +881,11 @@ __global__ __launch_bounds__(kSplitWaves * 64) void sah_split_kernel(SahArgs a, 
     constexpr uint32_t kRow = 8 * kBinWords + 1;
     __shared__ int sbins[64 * kRow];
     if (threadIdx.x == 0) { pf_n = 0; init_n = 0; }
+    // (the task record is loaded while the bins are staged: both depend on the task index only)
+    const uint32_t w = blockIdx.x * tpb + lane;
+    const bool valid = wave == 0 && lane < tpb && w < ntask;
+    SahTask T = {};
+    if (valid) T = a.tasks[cur][w];
     {
         const uint32_t first = blockIdx.x * tpb;
         const uint32_t ntk = min(tpb, ntask - first);
@@ -892,10 +899,6 @@ __global__ __launch_bounds__(kSplitWaves * 64) void sah_split_kernel(SahArgs a, 
     }
     __syncthreads();
     if (wave == 0) {
-    const uint32_t w = blockIdx.x * tpb + lane;
-    const bool valid = lane < tpb && w < ntask;
-    SahTask T = {};
-    if (valid) T = a.tasks[cur][w];
     const uint32_t count = T.end - T.start;
     const int bias = (T.flags & 1u) ? -2 * (int)a.B : (int)(2 * kSahCells);
 
@@ -1034,30 +1037,33 @@ __global__ __launch_bounds__(256) void sah_partition_kernel(SahArgs a, uint32_t 
     const uint32_t chunk = blockIdx.x, pos = chunk * kSahChunk + threadIdx.x;
     const uint32_t t = pos < a.M ? a.task_of[cur][pos] : kInactive;
     const uint32_t t_prev = (threadIdx.x > 0 && pos - 1 < a.M) ? a.task_of[cur][pos - 1] : kInactive;
-    uint32_t nloc;
-    const uint32_t local = sah_local_runs(t, t_prev, ws, &nloc);
-    if (nloc > kSahMaxLocal) return;   // reported by sah_bin_kernel
+    // all of the position's global loads up front (the scans below wait for LDS only)
+    const uint32_t id = pos < a.M ? a.ids[cur][pos] : 0u;
+    const uint32_t bin = pos < a.M ? a.binof[pos] : 0u;
+    const uint32_t cpre = a.chunk_prefix[chunk];
     SahSplit S = {};
     uint32_t start = 0;
-    bool left = false;
     if (t != kInactive) {
         S = a.splits[t];
         start = a.tasks[cur][t].start;
-        left = S.kind == 1 ? (a.binof[pos] <= S.plane) : (pos < S.mid);
     }
+    uint32_t nloc;
+    const uint32_t local = sah_local_runs(t, t_prev, ws, &nloc);
+    if (nloc > kSahMaxLocal) return;   // reported by sah_bin_kernel
+    const bool left = t != kInactive && (S.kind == 1 ? (bin <= S.plane) : (pos < S.mid));
     uint32_t total;
-    const uint32_t ex = block_excl_scan_u32<256>((t != kInactive && S.kind == 1 && left) ? 1u : 0u, ws, &total);
+    const uint32_t ex = block_excl_scan_lds<256>((t != kInactive && S.kind == 1 && left) ? 1u : 0u, ws, &total);
     if (threadIdx.x == 0 || t != t_prev) lfirst[local] = ex;
-    __syncthreads();
+    lds_barrier();
     if (pos >= a.M) return;
     if (t == kInactive) { a.task_of[nxt][pos] = kInactive; return; }
     uint32_t dest = pos;
     if (S.kind == 1) {
-        const uint32_t before = start < chunk * kSahChunk ? a.chunk_prefix[chunk] : 0u;
+        const uint32_t before = start < chunk * kSahChunk ? cpre : 0u;
         const uint32_t lr = before + (ex - lfirst[local]);
         dest = left ? start + lr : S.mid + ((pos - start) - lr);
     }
-    a.ids[nxt][dest] = a.ids[cur][pos];
+    a.ids[nxt][dest] = id;
     a.task_of[nxt][dest] = left ? S.left_id : S.right_id;
 }
 
