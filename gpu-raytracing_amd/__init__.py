@@ -109,6 +109,12 @@ def lib() -> ctypes.CDLL:
     if not os.path.exists(LIB_PATH):
         raise RtError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    # torch ships its own HIP runtime: it must be the one in the process before librt_amd.so resolves its HIP symbols
+    # (loaded the other way round, the two runtimes disagree about the device: hipErrorNoDevice at the first launch)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     vp, u32, i32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int
     L.rt_bu_memory_requirements.restype = ctypes.c_size_t
