@@ -19,11 +19,11 @@ static void NcclAssert(ncclResult_t r, const char* file, int line)
 
 void MultiGpuTracer::SetDevice(const Replica& r) const { check(hipSetDevice(r.device)); }
 
-MultiGpuTracer::MultiGpuTracer(int devices, int inflight)
+MultiGpuTracer::MultiGpuTracer(int devices, int inflight, bool virtual_devices) : virtual_(virtual_devices)
 {
     int have = 0;
     check(hipGetDeviceCount(&have));
-    if (devices < 1 || devices > have) {
+    if (devices < 1 || (!virtual_ && devices > have) || devices > 64) {
         fprintf(stderr, "gpu_assert: --gpus %d but %d device(s) visible\n", devices, have);
         exit(2);
     }
@@ -33,7 +33,7 @@ MultiGpuTracer::MultiGpuTracer(int devices, int inflight)
     }
     dev_.resize((size_t)devices);
     std::vector<int> list((size_t)devices);
-    for (int d = 0; d < devices; d++) dev_[(size_t)d].device = list[(size_t)d] = d;
+    for (int d = 0; d < devices; d++) dev_[(size_t)d].device = list[(size_t)d] = virtual_ ? 0 : d;
     slot_.resize((size_t)inflight);
     for (Slot& s : slot_) {
         s.dev.resize((size_t)devices);
@@ -47,10 +47,11 @@ MultiGpuTracer::MultiGpuTracer(int devices, int inflight)
             check(hipMalloc((void**)&x.num_tests, sizeof(uint64_t) * 4));
         }
         // one set of communicators per slot: RCCL orders the operations of a communicator, slots must stay independent
-        s.comms.resize((size_t)devices);
-        nccl_check(ncclCommInitAll(reinterpret_cast<ncclComm_t*>(s.comms.data()), devices, list.data()));
+        s.comms.assign((size_t)devices, nullptr);
+        if (!virtual_) nccl_check(ncclCommInitAll(reinterpret_cast<ncclComm_t*>(s.comms.data()), devices, list.data()));
         SetDevice(dev_[0]);
         check(hipMalloc((void**)&s.totals, sizeof(uint64_t) * 4));
+        check(hipEventCreateWithFlags(&s.gathered, hipEventDisableTiming));
         s.device_ms.assign((size_t)devices, 0.0f);
     }
 }
@@ -85,8 +86,11 @@ MultiGpuTracer::~MultiGpuTracer()
         (void)hipSetDevice(dev_[0].device);
         if (s.staging) (void)hipFree(s.staging);
         if (s.totals) (void)hipFree(s.totals);
+        if (s.gathered) (void)hipEventDestroy(s.gathered);
     }
-    for (Replica& r : dev_) {
+    for (size_t d = 0; d < dev_.size(); d++) {
+        Replica& r = dev_[d];
+        if (virtual_ && d > 0) break;          // virtual devices alias replica 0's scene
         (void)hipSetDevice(r.device);
         r.textures.Free();
         for (void* p : {(void*)r.in.triangles_in, (void*)r.in.triangles_out, (void*)r.in.nodes_out, r.in.scratch, (void*)r.attributes,
@@ -105,6 +109,12 @@ void MultiGpuTracer::UploadScene(const Scene& scene)
         Replica& r = dev_[d];
         hipStream_t st = slot_[0].dev[d].stream;
         SetDevice(r);
+        if (virtual_ && d > 0) {               // one scene, one tree: the virtual devices read replica 0's
+            const int keep = r.device;
+            r = dev_[0];
+            r.device = keep;
+            continue;
+        }
         // the four build buffers of Display() frame 0 (main.cu:226-240); the scratch covers either builder
         const size_t bu = BuMemoryRequirements(n), sah = SahMemoryRequirements(n);
         r.in.num_triangles = n;
@@ -142,7 +152,11 @@ float MultiGpuTracer::Build(const Arguments& args)
         if (sah_) RunSahBuild(r.in, args, x.stream); else RunBottomUpBuild(r.in, args, hybrid, x.stream);
         check(hipEventRecord(x.e1, x.stream));
     };
-    for (size_t d = 0; d < dev_.size(); d++) build_one(d);
+    for (size_t d = 0; d < (virtual_ ? 1 : dev_.size()); d++) build_one(d);
+    if (virtual_) {                            // (every virtual device's streams start behind the one build)
+        check(hipStreamSynchronize(slot_[0].dev[0].stream));
+        for (size_t d = 1; d < dev_.size(); d++) { check(hipEventRecord(slot_[0].dev[d].e0, slot_[0].dev[d].stream)); check(hipEventRecord(slot_[0].dev[d].e1, slot_[0].dev[d].stream)); }
+    }
     float worst = 0;
     for (size_t d = 0; d < dev_.size(); d++) {
         SetDevice(dev_[d]);
@@ -223,6 +237,8 @@ int MultiGpuTracer::TraceFrame(const Camera& camera, RenderType render_type, uns
     last_slot_ = si;
     Slot& s = slot_[(size_t)si];
     if (probe_slot_ == si) probe_slot_ = -1;          // the probe's events are about to be re-recorded
+    if (virtual_ && s.used)   // the slot's previous gather (copies on device 0's stream) must have read the parts before they are overwritten
+        for (unsigned d = 1; d < P; d++) check(hipStreamWaitEvent(s.dev[d].stream, s.gathered, 0));
     s.partition = use;
     s.timed = false;
     s.used = true;
@@ -260,6 +276,18 @@ int MultiGpuTracer::TraceFrame(const Camera& camera, RenderType render_type, uns
     // into GPU 0), and the counters are summed on device 0 (ncclReduce runs on a 1-device communicator too)
     GatherOp ops[kMaxGatherOps];
     const unsigned nops = GatherPlan(W, H, P, use, ops);
+    if (virtual_) {
+        // the same plan with copies: a sender's part is complete at its e1 event; device 0's slot stream waits for it and copies
+        for (unsigned k = 0; k < nops; k++) {
+            const GatherOp& o = ops[k];
+            if (o.kind != GatherOp::kRecvBand && o.kind != GatherOp::kRecvCompact) continue;
+            DevSlot& x = s.dev[o.device];
+            const uint8_t* src = (o.kind == GatherOp::kRecvBand ? x.frame : x.compact) + o.src_off;
+            uint8_t* dst = (o.kind == GatherOp::kRecvBand ? s.dev[0].frame : s.staging) + o.dst_off;
+            check(hipStreamWaitEvent(s.dev[0].stream, x.e1, 0));
+            check(hipMemcpyAsync(dst, src, o.bytes, hipMemcpyDeviceToDevice, s.dev[0].stream));
+        }
+    } else {
     nccl_check(ncclGroupStart());
     for (unsigned d = 0; d < P; d++) {
         DevSlot& x = s.dev[d];
@@ -277,6 +305,7 @@ int MultiGpuTracer::TraceFrame(const Camera& camera, RenderType render_type, uns
         nccl_check(ncclRecv(dst, o.bytes, ncclUint8, (int)o.device, comm0, s.dev[0].stream));
     }
     nccl_check(ncclGroupEnd());
+    }
 
     // ---- strips: de-interleave on device 0 (after the receives, on the same stream)
     SetDevice(dev_[0]);
@@ -288,6 +317,7 @@ int MultiGpuTracer::TraceFrame(const Camera& camera, RenderType render_type, uns
         else if (o.kind == GatherOp::kCopyCut)
             check(hipMemcpyAsync(s.dev[0].frame + o.dst_off, s.staging + o.src_off, o.bytes, hipMemcpyDeviceToDevice, s.dev[0].stream));
     }
+    if (virtual_) check(hipEventRecord(s.gathered, s.dev[0].stream));
     return si;
 }
 
@@ -324,5 +354,15 @@ void MultiGpuTracer::FrameToHost(std::vector<uint8_t>& out, int slot)
 void MultiGpuTracer::Counters(uint64_t out[4], int slot)
 {
     (void)Frame(slot);
-    check(hipMemcpy(out, slot_[(size_t)Resolve(slot)].totals, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost));
+    Slot& s = slot_[(size_t)Resolve(slot)];
+    if (!virtual_) {
+        check(hipMemcpy(out, s.totals, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost));
+        return;
+    }
+    for (int k = 0; k < 4; k++) out[k] = 0;
+    for (size_t d = 0; d < dev_.size(); d++) {       // (no RCCL in the virtual mode: the host adds the per-device counters)
+        uint64_t v[4];
+        check(hipMemcpy(v, s.dev[d].num_tests, sizeof v, hipMemcpyDeviceToHost));
+        for (int k = 0; k < 4; k++) out[k] += v[k];
+    }
 }

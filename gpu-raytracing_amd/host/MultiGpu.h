@@ -34,7 +34,11 @@ class MultiGpuTracer {
 public:
     // devices <= hipGetDeviceCount(); creates inflight streams per device and inflight sets of RCCL communicators
     // (ncclCommInitAll each)
-    explicit MultiGpuTracer(int devices, int inflight = 1);
+    // virtual_devices: all `devices` replicas live on device 0 (they share ONE scene and tree; each has its own streams and
+    // frame / compact buffers) and the gather runs as device-to-device copies ordered by events instead of RCCL send / recv.
+    // Not a scaling mode: it exists so that the P > 1 frame pipeline -- band offsets, strip ownership, staging slots, the
+    // de-interleave, frames in flight -- runs on hardware that has a single GPU (tests/test_gpu_golden.py).
+    explicit MultiGpuTracer(int devices, int inflight = 1, bool virtual_devices = false);
     ~MultiGpuTracer();
     MultiGpuTracer(const MultiGpuTracer&) = delete;
     MultiGpuTracer& operator=(const MultiGpuTracer&) = delete;
@@ -88,6 +92,7 @@ private:
         std::vector<ncclComm*> comms;   // [device]
         uint8_t* staging = nullptr;     // device 0: the P compact buffers back to back (strips)
         uint64_t* totals = nullptr;     // device 0: summed counters
+        hipEvent_t gathered = nullptr;  // virtual devices: device 0 has copied this slot's parts (the senders may overwrite them)
         Partition partition = Partition::kBands;
         std::vector<float> device_ms;
         bool timed = false, used = false;
@@ -101,6 +106,7 @@ private:
     unsigned num_triangles_ = 0;
     bool sah_ = false;
     int next_slot_ = 0, last_slot_ = 0;
+    bool virtual_ = false;
     Partition decided_ = Partition::kAuto;   // kAuto until the band costs of a probe frame are known
     int probe_slot_ = -1;                    // a frame issued as bands under kAuto whose times will decide
 };

@@ -5,7 +5,7 @@
 //
 //   rt_cli <file.obj> [--type sah|bottom-up|hybrid] [--pairs] [--splits] [--render depth|boxtests|tritests|material|lods|diffuse|texture|texturelit|shadows]
 //          [--width W] [--height H] [--spp N] [--yaw Y --pitch P --pos X Y Z] [--out frame.ppm] [--frames K]
-//          [--path "<ev>,<ev>,..."] [--rebuild] [--gpus N [--partition bands|strips|auto] [--inflight K]]
+//          [--path "<ev>,<ev>,..."] [--rebuild] [--gpus N [--partition bands|strips|auto] [--inflight K] [--virtual]]
 //   rt_cli - --grid G [--camera a|b] ...      (argv[1] stays the scene slot, as in the reference) the bench's synthetic scene: grid_mesh(G, 1) of
 //                                             gpu-raytracing_amd/scenes.py (G = 708: 1,002,528 triangles) and its camera A
 //                                             ("top-down") or B ("oblique"), SURVEY 8(d) -- the C++ host at the headline size
@@ -14,6 +14,8 @@
 // one row band (or interleaved strips) per device, one grouped RCCL send/recv per frame into device 0, counters summed by
 // ncclReduce.  --gpus 1 takes the same code path with a one-device communicator.  --inflight K (default 1 = the reference's
 // enqueue-wait-present loop): K frames in flight, frame f in slot f mod K (own streams, buffers and communicators per slot).
+// --virtual: the N devices are N virtual devices on GPU 0 (shared scene and tree, copies instead of RCCL): the P > 1 frame
+// pipeline on a one-GPU machine -- a functional check, not a scaling mode.
 //
 // --path: one comma-separated entry per frame (repeated cyclically when shorter than --frames); an entry is a
 // concatenation of events applied BEFORE that frame is traced, in the order the GLUT callbacks would have run:
@@ -100,12 +102,12 @@ static RenderType ParseRender(const std::string& s)
 
 // --gpus N: Display() with the frame partitioned across N devices (static camera; the scripted input path and --rebuild
 // belong to the single-device loop below)
-static int RunMultiGpu(int gpus, int inflight, Partition partition, const Scene& scene, const Arguments& args, const Camera& camera, int width,
+static int RunMultiGpu(int gpus, int inflight, bool virtual_devices, Partition partition, const Scene& scene, const Arguments& args, const Camera& camera, int width,
                        int height, int frames, unsigned spp, const std::string& out)
 {
     const unsigned n = (unsigned)scene.triangles.size();
     const bool hybrid = args.build_type == kHybrid, sah = args.build_type == kSAH;
-    MultiGpuTracer mg(gpus, inflight);
+    MultiGpuTracer mg(gpus, inflight, virtual_devices);
     mg.UploadScene(scene);
     const float build_ms = mg.Build(args);
     printf("%s time elapsed: %fms (%d replica%s, slowest)\n", sah ? "RunSahBuild" : "RunBottomUpBuild", build_ms, gpus, gpus == 1 ? "" : "s");
@@ -189,6 +191,7 @@ int main(int argc, char** argv)
     bool rebuild = false;
     int gpus = 0;                                              // 0: the single-device path of the reference
     int inflight = 1;                                          // --gpus N: frames in flight (MultiGpu.h)
+    bool virtual_devices = false;                              // --virtual: the N devices are virtual ones on device 0 (functional check of the P > 1 pipeline)
     Partition partition = Partition::kAuto;
     uint32_t grid = 0;                                         // --grid G: synthetic scene instead of argv[1]
     char grid_camera = 0;
@@ -208,6 +211,7 @@ int main(int argc, char** argv)
         else if (a == "--rebuild") { rebuild = true; }
         else if (a == "--gpus") { gpus = atoi(next(1)); i++; }
         else if (a == "--inflight") { inflight = atoi(next(1)); i++; }
+        else if (a == "--virtual") { virtual_devices = true; }
         else if (a == "--grid") { grid = (uint32_t)atoi(next(1)); i++; }
         else if (a == "--camera") { grid_camera = next(1)[0]; i++; }
         else if (a == "--partition") {
@@ -241,7 +245,7 @@ int main(int argc, char** argv)
     UpdateCamera(camera[0]);
     camera.toDevice();
 
-    if (gpus > 0) return RunMultiGpu(gpus, inflight, partition, scene, args, camera[0], width, height, frames, spp, out);
+    if (gpus > 0) return RunMultiGpu(gpus, inflight, virtual_devices, partition, scene, args, camera[0], width, height, frames, spp, out);
 
     // frame 0 of Display(): the four device buffers, upload, build, read back, count, verify (main.cu:226-259)
     BuildInput in{};
