@@ -21,6 +21,8 @@ def _scenes(scenes):
         "odd": scenes.grid_mesh(9, 4)[:161],
         "bigsoup": scenes.soup(20000, 9, size=0.6),             # large triangles: most want a split, the budget runs out
         "line": np.concatenate([scenes.grid_mesh(1, 1)[:1] + np.float32(i) * np.array([1, 0, 0] * 3, np.float32) for i in range(500)]),
+        # 59 octaves: trees 45+ levels deep against two level launches -- almost everything is built by sah_finish_kernel
+        "fractal": scenes.fractal_corner(3000, 5),
     }
 
 
@@ -44,7 +46,7 @@ def _gpu_sah(rt, tris, pairs, splits=False):
 
 @pytest.mark.parametrize("splits", [False, True])
 @pytest.mark.parametrize("pairs", [False, True])
-@pytest.mark.parametrize("name", ["grid24", "grid100", "soup65536", "flat20", "dups4096", "one", "two", "three", "odd", "line", "bigsoup"])
+@pytest.mark.parametrize("name", ["grid24", "grid100", "soup65536", "flat20", "dups4096", "one", "two", "three", "odd", "line", "bigsoup", "fractal"])
 def test_sah_build_bit_exact(name, pairs, splits, rt, scenes, ora):
     from helpers import assert_nodes_equal
     tris = _scenes(scenes)[name]
