@@ -1352,6 +1352,8 @@ __global__ __launch_bounds__(kFinThreads) void sah_finish_kernel(SahArgs a, uint
     __shared__ int sb[8 * kBinWords];        // the task's bins: the global form (max words complemented) while they fill
     __shared__ int scb[2][12];               // the children's boxes [side][p box 6, c box 6], ordered ints
     __shared__ uint32_t ws[8];
+    __shared__ float c_score[8];
+    __shared__ uint32_t c_ln[8];
     const uint32_t tid = threadIdx.x;
     for (uint32_t task = blockIdx.x; task < ntask; task += gridDim.x) {
         if (tid == 0) {
@@ -1402,9 +1404,44 @@ __global__ __launch_bounds__(kFinThreads) void sah_finish_kernel(SahArgs a, uint
                     if (wd < 12 && (wd % 6) >= 3) sb[tid] = ~sb[tid];
                 }
                 __syncthreads();
+                // eight lanes score the seven planes (boxes left / right of plane i are merges of ordered ints: exact and order-free;
+                // the score is SelectPlane's own expression), lane 0 picks like the serial sweep: right to left, strict <
+                if (tid < 8) {
+                    const uint32_t i = tid;
+                    float score = 3.402823466e+38f;
+                    uint32_t lni = 0;
+                    if (i < 7) {
+                        int L[6] = {kEmptyLo, kEmptyLo, kEmptyLo, kEmptyHi, kEmptyHi, kEmptyHi}, R[6] = {kEmptyLo, kEmptyLo, kEmptyLo, kEmptyHi, kEmptyHi, kEmptyHi};
+                        uint32_t ln = 0, rn = 0;
+#pragma unroll
+                        for (uint32_t bq = 0; bq < 8; bq++) {
+                            if (bq <= i) { ibox_merge(L, sb + bq * kBinWords); ln += (uint32_t)sb[bq * kBinWords + 12]; }
+                            else { ibox_merge(R, sb + bq * kBinWords); rn += (uint32_t)sb[bq * kBinWords + 12]; }
+                        }
+                        float fl[6], fr[6];
+                        ibox_to_float(L, fl);
+                        ibox_to_float(R, fr);
+                        score = sah_sa(fl) * (float)ln + sah_sa(fr) * (float)rn;
+                        lni = (ln && rn) ? ln : 0u;
+                    }
+                    c_score[i] = score; c_ln[i] = lni;
+                }
+                __syncthreads();
                 if (tid == 0) {
                     uint32_t kind = 2, plane = 0, mid = T.start + (count >> 1);
-                    sah_select_plane(sb, T.start, kind, plane, mid, scb);
+                    float best = 3.402823466e+38f;
+                    int pl = -1;
+#pragma unroll
+                    for (int i = 6; i >= 0; i--)
+                        if (c_ln[i] && c_score[i] < best) { best = c_score[i]; pl = i; }
+                    if (pl >= 0) {
+                        kind = 1; plane = (uint32_t)pl; mid = T.start + c_ln[pl];
+                        for (int bq = 0; bq < 8; bq++) {
+                            int* dst = &scb[bq <= pl ? 0 : 1][0];
+                            ibox_merge(dst, sb + bq * kBinWords);
+                            ibox_merge(dst + 6, sb + bq * kBinWords + 6);
+                        }
+                    }
                     s_kind = kind; s_plane = plane; s_mid = mid;
                 }
             }
@@ -1443,10 +1480,12 @@ __global__ __launch_bounds__(kFinThreads) void sah_finish_kernel(SahArgs a, uint
                     running += total;
                 }
             }
-            // the ids written above are read by OTHER threads of this workgroup when a child is popped: complete and
-            // visible before the barrier
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+            // the ids written above are read by OTHER threads of this workgroup when a child is popped: every wave drains its
+            // stores (the vector L1 writes through to this XCD's L2), the workgroup meets, the L1 is invalidated -- the reader is
+            // on the same CU, so no L2 write-back (an agent-scope release flushes every dirty line of the XCD's L2)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             if (tid == 0) {
                 const int bias = (T.flags & 1u) ? -2 * (int)a.B : (int)(2 * kSahCells);
                 const uint32_t child_index = (uint32_t)(bias + 2 * (int)mid);
