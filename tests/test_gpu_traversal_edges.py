@@ -247,6 +247,19 @@ def test_prefetch_instantiation_full_stack_wide_nodes_and_bands(rt, scenes, ora)
         assert (gc == oc[:2]).all(), f"width {width}"
         assert (gi == oi).all()
     gb = _gpu_bu(rt, tris)
+    # interleaved strips (rt_trace_strips: the multi-GPU partition's compact output) through the same instantiation
+    import torch
+    full, _ = ora.trace(b["leaves"], b["nodes"], 0, 2, cam, 130, 101, render_type=0)
+    for first, stride in ((0, 3), (2, 3)):
+        nstr = len(range(first, (101 + 7) // 8, stride))
+        compact = torch.zeros(nstr * 8 * 130 * 4, dtype=torch.uint8, device="cuda")
+        rt.Trace(gb["inp"].triangles_out, gb["inp"].nodes_out, compact, (130, 101), rt.to_device(cam), 0, 2, strips=(8, first, stride),
+                 num_primitives=BIG)
+        torch.cuda.synchronize()
+        got = compact.cpu().numpy().reshape(nstr * 8, 130, 4)
+        for j, st in enumerate(range(first, (101 + 7) // 8, stride)):
+            rows_in = min(8, 101 - st * 8)
+            assert (got[j * 8: j * 8 + rows_in] == full[st * 8: st * 8 + rows_in]).all(), f"strip {st}"
     for rows, spp in (((13, 50), 1), ((0, 101), 16)):
         oi, oc = ora.trace(b["leaves"], b["nodes"], 0, 2, cam, 130, 101, render_type=0, rows=rows, spp=spp)
         gi, gc = gpu_trace(gb, cam, 130, 101, 0, rows=rows, spp=spp, num_primitives=BIG)
