@@ -284,8 +284,8 @@ const char* rt_error_string(int code)
 const char* rt_version_string(void)
 {
     return "rt_amd gfx950 | sort: LSD 3x10bit Morton keys (4x8bit generic), tile 4096 | lbvh: LDS agglomerative, 512 leaves/wg (4 wg per CU), leaves and node pairs staged in LDS and streamed out + one chained launch for all upper levels (last-arriver tickets, fan 48 or 64; passes of <= 1023 open roots by range searches over sparse tables), hybrid SAH top | "
-           "sah: 4x4x4 grid + level-synchronous binned SAH, wave-per-task below 64 items, pairs, splits | "
-           "trace: wave64 8x8 tiles, two-phase schedule, LDS stack 16, XCD chunks of 8 workgroups";
+           "sah: 4x4x4 grid + level-synchronous binned SAH (fixed launch count, no host round trip), workgroup-per-task stragglers, wave-per-task below 64 items, pairs, splits | "
+           "trace: wave64 8x8 tiles, two-phase schedule, LDS stack 16, XCD chunks of 8 workgroups, pair prefetch from 8M primitives, counters through 16-row slots";
 }
 
 }  // extern "C"
